@@ -1,0 +1,138 @@
+/* pero_hip.h - C ABI of libpero_hip.so: hand-written gfx950 (MI355X / CDNA4) kernels for the
+ * per-step hot path of DCGM/pero-pretraining (masked / joint-embedding pre-training over text-line
+ * images).
+ *
+ * The reference is pure Python and has no FFI of its own for this path: every function below
+ * replaces a PyTorch library call made by the reference (cited per function, paths relative to
+ * /root/reference/pero_pretraining/).  A Python caller binds this header with ctypes (see
+ * INTEGRATION.md); nothing in the signatures is a torch type.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (workspaces included); the library never
+ *     allocates, frees or synchronises;
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it;
+ *   - `dtype`: PERO_F32 (parity mode, exact f32 MFMA / VALU arithmetic) or PERO_BF16 (bf16 storage
+ *     and MFMA operands, f32 accumulation, f32 statistics);
+ *   - return value 0 = ok, negative = PERO_E_*; text via pero_last_error() (thread local);
+ *   - re-entrant, callable from any thread (autograd worker threads call the backward entry points).
+ */
+#ifndef PERO_HIP_H
+#define PERO_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PERO_F32 0
+#define PERO_BF16 1
+
+#define PERO_OK 0
+#define PERO_E_INVALID (-1)   /* bad argument (shape, alignment, null pointer) */
+#define PERO_E_UNSUPPORTED (-2)
+#define PERO_E_LAUNCH (-3)    /* hipLaunch / runtime error; message holds hipGetErrorString */
+
+/* epilogue / mode flags of pero_gemm */
+#define PERO_GEMM_RELU 1        /* C = max(C, 0) after bias/residual */
+#define PERO_GEMM_ATOMIC 2      /* f32 C only: atomically add the tile into C (split-K safe) */
+#define PERO_GEMM_ACCUM 4       /* f32 C only: C += result (non-atomic) */
+#define PERO_GEMM_TRANS_A 8     /* A is stored [K][M] (lda = row pitch of that storage) */
+#define PERO_GEMM_TRANS_B 16    /* B is stored [K][N]; default B is stored [N][K] (Linear weight layout) */
+#define PERO_GEMM_FORCE_GENERIC 32 /* testing: take the exact-f32 generic kernel even when the fast bf16 kernel applies */
+
+const char* pero_last_error(void);
+int pero_abi_version(void);
+
+/* ---- front end ------------------------------------------------------------------------------
+ * images u8 (N,H,W,C) -> patch rows (N*S, C*H*P) ordered (c,h,p), value/255, masked patches replaced
+ * by the (C,H,P) noise tile.  Replaces BatchOperator._prepare_batch_images
+ * (masked_pretraining/batch_operator.py:17-20) + TransformerEncoder.mask (models/transformers.py:53-68)
+ * + the im2col of Conv2d(kernel=stride=(H,P)) (models/transformers.py:99-107).  mask may be null. */
+int pero_patches_from_u8(const uint8_t* images, const int64_t* mask, const float* tile, void* patches,
+                         int64_t N, int64_t H, int64_t W, int64_t C, int64_t P, int dtype, void* stream);
+/* same from float NCHW images (the reference's own model input layout) */
+int pero_patches_from_f32(const float* images_nchw, const int64_t* mask, const float* tile, void* patches,
+                          int64_t N, int64_t H, int64_t W, int64_t C, int64_t P, int dtype, void* stream);
+/* in-place TransformerEncoder.mask on float NCHW images (models/transformers.py:53-68) */
+int pero_apply_mask_f32(float* images_nchw, const int64_t* mask, const float* tile,
+                        int64_t N, int64_t H, int64_t W, int64_t C, int64_t P, void* stream);
+
+/* ---- GEMM -------------------------------------------------------------------------------------
+ * C[b] = alpha * op(A[b]) * op(B[b])^T (+ bias[n]) (+ residual) (relu) (* (gate > 0)),  M x N x K.
+ * Replaces torch.nn.Linear / F.linear / torch.matmul / Conv2d-as-GEMM call sites:
+ * models/transformers.py:37-43,99 ; masked_pretraining/model.py:102 ; models/autoencoders.py:214 ;
+ * joint_embedding_pretraining/losses.py:42,77 and their autograd backward products.
+ * Batch b = bo * batch_inner + bi; operand base offset = bo * s?o + bi * s?i (elements).
+ * in_dtype: A, B (and residual, gate); out_dtype: C.  bias is f32.  k_split > 1 needs PERO_GEMM_ATOMIC. */
+int pero_gemm(const void* A, const void* B, void* C, const float* bias, const void* residual, const void* gate,
+              int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int64_t ldg,
+              int64_t batch, int64_t batch_inner,
+              int64_t sAo, int64_t sAi, int64_t sBo, int64_t sBi, int64_t sCo, int64_t sCi,
+              float alpha, int flags, int k_split, int in_dtype, int out_dtype, void* stream);
+
+/* ---- LayerNorm (+ positional encoding) --------------------------------------------------------------
+ * y = (x - mean) * rstd * gamma + beta (+ pe[offsets[row / S] + row % S]) ; rows x d.
+ * Replaces torch.nn.LayerNorm (models/transformers.py:28,83-84 and the norm1/norm2 of
+ * TransformerEncoderLayer) and PositionalEncoding.forward (models/transformers.py:174-188).
+ * pe (f32 [max_len][d]) and offsets (int64 [rows/S]) may be null (offsets null => offset 0). */
+int pero_layernorm_fwd(const void* x, const float* gamma, const float* beta, const float* pe, const int64_t* offsets,
+                       void* y, float* mean, float* rstd, int64_t rows, int64_t d, int64_t S, float eps,
+                       int dtype, void* stream);
+/* dx, and dgamma/dbeta/dxsum ACCUMULATED atomically into f32 [d] buffers (dxsum = column sums of dx,
+ * i.e. the bias gradient of the Linear that produced x; may be null) */
+int pero_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                       void* dx, float* dgamma, float* dbeta, float* dxsum, int64_t rows, int64_t d,
+                       int dtype, void* stream);
+
+/* ---- softmax over the last dim (attention probabilities; torch SDPA inside
+ * TransformerEncoderLayer._sa_block, models/transformers.py:86) ---------------------------------------
+ * p = softmax(scale * s) row-wise; s is f32 (rows, cols), p has `dtype` */
+int pero_softmax_fwd(const float* s, void* p, int64_t rows, int64_t cols, float scale, int dtype, void* stream);
+/* ds = scale * p * (dp - sum_j p*dp); dp is f32, p and ds have `dtype` */
+int pero_softmax_bwd(const void* p, const float* dp, void* ds, int64_t rows, int64_t cols, float scale, int dtype,
+                     void* stream);
+
+/* ---- masked cross entropy (masked_pretraining/model.py:72-95) -------------------------------------------
+ * logits (rows, V); labels, mask int64 (rows).  loss_out[0] = mean CE over mask==1 rows
+ * (+ unmasked_weight * mean CE over mask==0 & label>=0 rows when unmasked_weight >= 0; pass a negative
+ * value for "None").  dlogits (same dtype/shape as logits, may be null) = d loss / d logits.
+ * work: f32 workspace of at least rows + 8 elements.  Empty selections give NaN like the reference. */
+int pero_masked_ce(const void* logits, const int64_t* labels, const int64_t* mask, float unmasked_weight,
+                   float* loss_out, void* dlogits, float* work, int64_t rows, int64_t V, int dtype, void* stream);
+
+/* ---- reductions / elementwise ---------------------------------------------------------------------- */
+/* out[n] += sum_m x[m][n]  (bias gradients); out f32 */
+int pero_colsum(const void* x, float* out, int64_t rows, int64_t cols, int64_t ld, int dtype, void* stream);
+/* f32 -> bf16 copy (low-precision weight copies) */
+int pero_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream);
+int pero_cast_bf16_f32(const void* src, float* dst, int64_t n, void* stream);
+/* y = x * scale (in place allowed), dtype elements */
+int pero_scale(void* x, int64_t n, float scale, int dtype, void* stream);
+
+/* ---- Adam (torch.optim.Adam defaults: masked_pretraining/train.py:146) ----------------------------------
+ * one launch over a flat f32 parameter / gradient / moment buffer; `step` is 1-based; optionally also
+ * writes the bf16 copy of the updated parameters (p_bf16 may be null). */
+int pero_adam_step(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr,
+                   float beta1, float beta2, float eps, int64_t step, float grad_scale, void* stream);
+
+/* ---- quantizers (models/autoencoders.py:212-217 ; scripts/produce_kmeans_labels.py:72-76) ---------------
+ * indices[m] = argmin_k ( sum(x_m^2) + sum(e_k^2) - 2 x_m . e_k )  in exact f32, first minimum wins.
+ * x (M,D) f32, codebook (K,D) f32, indices int64 (M).  best_dist (f32, M) may be null.
+ * work: f32 workspace of at least M + K elements (row / code squared norms). */
+int pero_vq_argmin(const float* x, const float* codebook, int64_t* indices, float* best_dist, float* work,
+                   int64_t M, int64_t K, int64_t D, void* stream);
+/* quantized[m] = x[m] + (codebook[indices[m]] - x[m])  (straight-through arithmetic, autoencoders.py:239) */
+int pero_vq_gather(const float* x, const float* codebook, const int64_t* indices, float* quantized,
+                   int64_t M, int64_t D, void* stream);
+
+/* ---- row gather / scatter by index (boolean-mask selections of the losses) ----------------------------- */
+/* dst[i] = src[index[i]] for i < n_idx, zero rows for n_idx <= i < n_rows_out (padding) */
+int pero_gather_rows(const void* src, const int64_t* index, void* dst, int64_t n_idx, int64_t n_rows_out,
+                     int64_t d, int dtype, void* stream);
+/* dst[index[i]] += src[i] (indices unique) */
+int pero_scatter_add_rows(const void* src, const int64_t* index, void* dst, int64_t n_idx, int64_t d,
+                          int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

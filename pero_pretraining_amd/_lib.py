@@ -1,0 +1,72 @@
+"""ctypes binding of libpero_hip.so (the C ABI declared in include/pero_hip.h).
+
+The product path has no fallback: if the shared library is missing this module raises at import of
+the first op, and every non-zero return code becomes a Python exception carrying pero_last_error().
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpero_hip.so")
+
+PERO_F32, PERO_BF16 = 0, 1
+GEMM_RELU, GEMM_ATOMIC, GEMM_ACCUM, GEMM_TRANS_A, GEMM_TRANS_B, GEMM_FORCE_GENERIC = 1, 2, 4, 8, 16, 32
+
+_vp, _i64, _i32, _f32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float
+
+# name -> argtypes (all functions return int unless noted)
+SIGNATURES = {
+    "pero_patches_from_u8": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i32, _vp],
+    "pero_patches_from_f32": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i32, _vp],
+    "pero_apply_mask_f32": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp],
+    "pero_gemm": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
+                  _i64, _i64, _i64, _i64, _i64, _i64, _f32, _i32, _i32, _i32, _i32, _vp],
+    "pero_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _f32, _i32, _vp],
+    "pero_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp],
+    "pero_softmax_fwd": [_vp, _vp, _i64, _i64, _f32, _i32, _vp],
+    "pero_softmax_bwd": [_vp, _vp, _vp, _i64, _i64, _f32, _i32, _vp],
+    "pero_masked_ce": [_vp, _vp, _vp, _f32, _vp, _vp, _vp, _i64, _i64, _i32, _vp],
+    "pero_colsum": [_vp, _vp, _i64, _i64, _i64, _i32, _vp],
+    "pero_cast_f32_bf16": [_vp, _vp, _i64, _vp],
+    "pero_cast_bf16_f32": [_vp, _vp, _i64, _vp],
+    "pero_scale": [_vp, _i64, _f32, _i32, _vp],
+    "pero_adam_step": [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _i64, _f32, _vp],
+    "pero_vq_argmin": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp],
+    "pero_vq_gather": [_vp, _vp, _vp, _vp, _i64, _i64, _vp],
+    "pero_gather_rows": [_vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp],
+    "pero_scatter_add_rows": [_vp, _vp, _vp, _i64, _i64, _i32, _vp],
+}
+
+
+class PeroHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the ctypes handle.  Raises if the HIP library has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PeroHipError(
+                f"{LIB_PATH} not found: build it with `make -C {os.path.join(_HERE, 'csrc')}` "
+                "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+        h = ctypes.CDLL(LIB_PATH)
+        h.pero_last_error.restype = ctypes.c_char_p
+        h.pero_last_error.argtypes = []
+        h.pero_abi_version.restype = ctypes.c_int
+        h.pero_abi_version.argtypes = []
+        for name, args in SIGNATURES.items():
+            fn = getattr(h, name)
+            fn.restype = ctypes.c_int
+            fn.argtypes = args
+        _lib = h
+    return _lib
+
+
+def call(name, *args):
+    rc = getattr(lib(), name)(*args)
+    if rc != 0:
+        raise PeroHipError(f"{name} failed ({rc}): {lib().pero_last_error().decode()}")

@@ -1,0 +1,61 @@
+// Shared device/host helpers for libpero_hip (gfx950 only: wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/pero_hip.h"
+
+typedef unsigned short bf16raw;                                    // bf16 bit pattern in memory
+typedef __bf16 bf8v __attribute__((ext_vector_type(8)));           // MFMA bf16 operand fragment
+typedef short s4v __attribute__((ext_vector_type(4)));
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+#define LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
+
+__device__ __forceinline__ float bf2f(bf16raw b) { return __uint_as_float(((unsigned)b) << 16); }
+__device__ __forceinline__ bf16raw f2bf(float f) {  // round-to-nearest-even, NaN stays NaN (v_cvt_pk_bf16_f32)
+  __bf16 h = (__bf16)f;
+  return __builtin_bit_cast(bf16raw, h);
+}
+__device__ __forceinline__ unsigned pack2bf(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+  static __device__ __forceinline__ float ld(const float* p) { return *p; }
+  static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct Elem<bf16raw> {
+  static __device__ __forceinline__ float ld(const bf16raw* p) { return bf2f(*p); }
+  static __device__ __forceinline__ void st(bf16raw* p, float v) { *p = f2bf(v); }
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// host side ------------------------------------------------------------------------------------
+void pero_set_error(const char* fmt, ...);
+#define PERO_REQUIRE(cond, ...)                   \
+  do {                                            \
+    if (!(cond)) {                                \
+      pero_set_error(__VA_ARGS__);                \
+      return PERO_E_INVALID;                      \
+    }                                             \
+  } while (0)
+#define PERO_CHECK_LAUNCH(name)                                                     \
+  do {                                                                              \
+    hipError_t e_ = hipGetLastError();                                              \
+    if (e_ != hipSuccess) {                                                         \
+      pero_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));         \
+      return PERO_E_LAUNCH;                                                         \
+    }                                                                               \
+  } while (0)
+static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }

@@ -1,0 +1,246 @@
+// Front end (u8 line images -> patch rows), casts, Adam, row gather / scatter.  All HBM-bound.
+#include "common.hpp"
+
+// ---------------------------------------------------------------------------------------------
+// patch rows from u8 NHWC line images.  One block = one line x 16 consecutive patches: the
+// 40 x (16*P*C)-byte sub-image is read once with coalesced 4-byte loads into LDS, then written out as
+// whole (c,h,p)-ordered patch rows (contiguous C*H*P elements per patch).
+// ---------------------------------------------------------------------------------------------
+#define PT_TOK 16
+template <typename T>
+__global__ __launch_bounds__(256) void patches_u8_k(const uint8_t* img, const int64_t* mask, const float* tile, T* out,
+                                                    int H, int W, int C, int P, int S) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int n = blockIdx.y, s0 = blockIdx.x * PT_TOK;
+  const int ntok = (S - s0) < PT_TOK ? (S - s0) : PT_TOK;
+  const int rowbytes = ntok * P * C;
+  const long long rowpitch = (long long)W * C;
+  const uint8_t* src = img + ((long long)n * H) * rowpitch + (long long)s0 * P * C;
+  const int ldsp = PT_TOK * P * C;
+  if ((rowbytes & 3) == 0 && (rowpitch & 3) == 0 && ((s0 * P * C) & 3) == 0 && ((uintptr_t)img & 3) == 0) {
+    const int rw = rowbytes >> 2;
+    for (int i = threadIdx.x; i < H * rw; i += 256) {
+      const int h = i / rw, b = i - h * rw;
+      *(unsigned*)(lds + h * ldsp + 4 * b) = *(const unsigned*)(src + h * rowpitch + 4 * b);
+    }
+  } else {
+    for (int i = threadIdx.x; i < H * rowbytes; i += 256) {
+      const int h = i / rowbytes, b = i - h * rowbytes;
+      lds[h * ldsp + b] = src[h * rowpitch + b];
+    }
+  }
+  __syncthreads();
+  const int groups = ntok * C * H;  // one group = the P pixels of one (token, c, h)
+  const int pd = C * H * P;
+  for (int gidx = threadIdx.x; gidx < groups; gidx += 256) {
+    const int tok = gidx / (C * H), ch = gidx - tok * (C * H);
+    const int c = ch / H, h = ch - c * H;
+    const bool masked = mask && mask[(long long)n * S + s0 + tok] == 1;
+    T* o = out + ((long long)n * S + s0 + tok) * pd + (long long)ch * P;
+    for (int e = 0; e < P; e++) {
+      const float v = masked ? tile[ch * P + e] : (float)lds[h * ldsp + (tok * P + e) * C + c] / 255.0f;
+      Elem<T>::st(o + e, v);
+    }
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void patches_f32_k(const float* img, const int64_t* mask, const float* tile, T* out,
+                                                     long long total, int H, int W, int C, int P, int S) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;  // index over (n, s, c, h, p)
+  if (i >= total) return;
+  const int p = (int)(i % P);
+  long long r = i / P;
+  const int h = (int)(r % H); r /= H;
+  const int c = (int)(r % C); r /= C;
+  const int s = (int)(r % S);
+  const long long n = r / S;
+  const bool masked = mask && mask[n * S + s] == 1;
+  const float v = masked ? tile[(c * H + h) * P + p] : img[((n * C + c) * H + h) * W + (long long)s * P + p];
+  Elem<T>::st(out + i, v);
+}
+__global__ __launch_bounds__(256) void apply_mask_k(float* img, const int64_t* mask, const float* tile, long long total,
+                                                    int H, int W, int C, int P) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;  // index over (n, c, h, w)
+  if (i >= total) return;
+  const int w = (int)(i % W);
+  long long r = i / W;
+  const int h = (int)(r % H); r /= H;
+  const int c = (int)(r % C);
+  const long long n = r / C;
+  if (mask[n * (W / P) + w / P] == 1) img[i] = tile[(c * H + h) * P + (w % P)];
+}
+
+extern "C" int pero_patches_from_u8(const uint8_t* images, const int64_t* mask, const float* tile, void* patches,
+                                    int64_t N, int64_t H, int64_t W, int64_t C, int64_t P, int dtype, void* stream) {
+  PERO_REQUIRE(images && patches && (tile || !mask), "pero_patches_from_u8: null pointer");
+  PERO_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && P > 0 && W % P == 0 && N < 65536, "pero_patches_from_u8: bad sizes (W %% P must be 0)");
+  const int S = (int)(W / P);
+  const size_t lds = (size_t)H * PT_TOK * P * C;
+  PERO_REQUIRE(lds <= 65536, "pero_patches_from_u8: H*16*P*C = %zu bytes exceeds the LDS staging budget", lds);
+  dim3 grid((unsigned)((S + PT_TOK - 1) / PT_TOK), (unsigned)N), block(256);
+  if (dtype == PERO_F32) hipLaunchKernelGGL((patches_u8_k<float>), grid, block, lds, (hipStream_t)stream, images, mask, tile, (float*)patches, (int)H, (int)W, (int)C, (int)P, S);
+  else if (dtype == PERO_BF16) hipLaunchKernelGGL((patches_u8_k<bf16raw>), grid, block, lds, (hipStream_t)stream, images, mask, tile, (bf16raw*)patches, (int)H, (int)W, (int)C, (int)P, S);
+  else PERO_REQUIRE(false, "pero_patches_from_u8: bad dtype");
+  PERO_CHECK_LAUNCH("pero_patches_from_u8");
+  return PERO_OK;
+}
+extern "C" int pero_patches_from_f32(const float* images, const int64_t* mask, const float* tile, void* patches,
+                                     int64_t N, int64_t H, int64_t W, int64_t C, int64_t P, int dtype, void* stream) {
+  PERO_REQUIRE(images && patches && (tile || !mask), "pero_patches_from_f32: null pointer");
+  PERO_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && P > 0 && W % P == 0, "pero_patches_from_f32: bad sizes");
+  const long long total = (long long)N * C * H * W;
+  dim3 grid((unsigned)((total + 255) / 256)), block(256);
+  if (dtype == PERO_F32) hipLaunchKernelGGL((patches_f32_k<float>), grid, block, 0, (hipStream_t)stream, images, mask, tile, (float*)patches, total, (int)H, (int)W, (int)C, (int)P, (int)(W / P));
+  else if (dtype == PERO_BF16) hipLaunchKernelGGL((patches_f32_k<bf16raw>), grid, block, 0, (hipStream_t)stream, images, mask, tile, (bf16raw*)patches, total, (int)H, (int)W, (int)C, (int)P, (int)(W / P));
+  else PERO_REQUIRE(false, "pero_patches_from_f32: bad dtype");
+  PERO_CHECK_LAUNCH("pero_patches_from_f32");
+  return PERO_OK;
+}
+extern "C" int pero_apply_mask_f32(float* images, const int64_t* mask, const float* tile, int64_t N, int64_t H, int64_t W,
+                                   int64_t C, int64_t P, void* stream) {
+  PERO_REQUIRE(images && mask && tile, "pero_apply_mask_f32: null pointer");
+  PERO_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && P > 0 && W % P == 0, "pero_apply_mask_f32: bad sizes");
+  const long long total = (long long)N * C * H * W;
+  hipLaunchKernelGGL(apply_mask_k, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, images, mask, tile, total, (int)H, (int)W, (int)C, (int)P);
+  PERO_CHECK_LAUNCH("pero_apply_mask_f32");
+  return PERO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// casts / scale
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cast_f32_bf16_k(const float* src, bf16raw* dst, long long n) {
+  const long long stride = (long long)gridDim.x * 256 * 8;
+  for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 8; i < n; i += stride) {
+    if (i + 8 <= n) {
+      const f4v a = *(const f4v*)(src + i), b = *(const f4v*)(src + i + 4);
+      uint4 o;
+      o.x = pack2bf(a[0], a[1]); o.y = pack2bf(a[2], a[3]); o.z = pack2bf(b[0], b[1]); o.w = pack2bf(b[2], b[3]);
+      *(uint4*)(dst + i) = o;
+    } else {
+      for (long long j = i; j < n; j++) dst[j] = f2bf(src[j]);
+    }
+  }
+}
+__global__ __launch_bounds__(256) void cast_bf16_f32_k(const bf16raw* src, float* dst, long long n) {
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i] = bf2f(src[i]);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void scale_k(T* x, long long n, float s) {
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) Elem<T>::st(x + i, Elem<T>::ld(x + i) * s);
+}
+static unsigned grid_for(long long n, int per) {
+  long long b = (n + (long long)256 * per - 1) / ((long long)256 * per);
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+extern "C" int pero_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream) {
+  PERO_REQUIRE(src && dst && n > 0 && aligned16(src) && aligned16(dst), "pero_cast_f32_bf16: bad arguments");
+  hipLaunchKernelGGL(cast_f32_bf16_k, dim3(grid_for(n, 8)), dim3(256), 0, (hipStream_t)stream, src, (bf16raw*)dst, (long long)n);
+  PERO_CHECK_LAUNCH("pero_cast_f32_bf16");
+  return PERO_OK;
+}
+extern "C" int pero_cast_bf16_f32(const void* src, float* dst, int64_t n, void* stream) {
+  PERO_REQUIRE(src && dst && n > 0, "pero_cast_bf16_f32: bad arguments");
+  hipLaunchKernelGGL(cast_bf16_f32_k, dim3(grid_for(n, 1)), dim3(256), 0, (hipStream_t)stream, (const bf16raw*)src, dst, (long long)n);
+  PERO_CHECK_LAUNCH("pero_cast_bf16_f32");
+  return PERO_OK;
+}
+extern "C" int pero_scale(void* x, int64_t n, float scale, int dtype, void* stream) {
+  PERO_REQUIRE(x && n > 0, "pero_scale: bad arguments");
+  if (dtype == PERO_F32) hipLaunchKernelGGL((scale_k<float>), dim3(grid_for(n, 1)), dim3(256), 0, (hipStream_t)stream, (float*)x, (long long)n, scale);
+  else if (dtype == PERO_BF16) hipLaunchKernelGGL((scale_k<bf16raw>), dim3(grid_for(n, 1)), dim3(256), 0, (hipStream_t)stream, (bf16raw*)x, (long long)n, scale);
+  else PERO_REQUIRE(false, "pero_scale: bad dtype");
+  PERO_CHECK_LAUNCH("pero_scale");
+  return PERO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Adam over one flat buffer.  Algorithmic traffic: 16 B read + 12 B written per parameter (+2 B bf16 copy).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_k(float* p, const float* g, float* m, float* v, bf16raw* pb, long long n, float lr_bc1,
+                                              float b1, float b2, float omb1, float omb2, float eps, float inv_sqrt_bc2, float gscale) {
+  const long long stride = (long long)gridDim.x * 256 * 4;
+  for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
+    if (i + 4 <= n) {
+      f4v pp = *(f4v*)(p + i), gg = *(const f4v*)(g + i), mm = *(f4v*)(m + i), vv = *(f4v*)(v + i);
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const float ge = gg[e] * gscale;
+        mm[e] = mm[e] * b1 + omb1 * ge;
+        vv[e] = vv[e] * b2 + omb2 * ge * ge;
+        const float denom = sqrtf(vv[e]) * inv_sqrt_bc2 + eps;
+        pp[e] = pp[e] - lr_bc1 * (mm[e] / denom);
+      }
+      *(f4v*)(p + i) = pp; *(f4v*)(m + i) = mm; *(f4v*)(v + i) = vv;
+      if (pb) { uint2 o; o.x = pack2bf(pp[0], pp[1]); o.y = pack2bf(pp[2], pp[3]); *(uint2*)(pb + i) = o; }
+    } else {
+      for (long long j = i; j < n; j++) {
+        const float ge = g[j] * gscale;
+        const float mj = m[j] * b1 + omb1 * ge;
+        const float vj = v[j] * b2 + omb2 * ge * ge;
+        m[j] = mj; v[j] = vj;
+        p[j] = p[j] - lr_bc1 * (mj / (sqrtf(vj) * inv_sqrt_bc2 + eps));
+        if (pb) pb[j] = f2bf(p[j]);
+      }
+    }
+  }
+}
+extern "C" int pero_adam_step(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr, float beta1,
+                              float beta2, float eps, int64_t step, float grad_scale, void* stream) {
+  PERO_REQUIRE(p && g && m && v && n > 0 && step >= 1, "pero_adam_step: bad arguments");
+  PERO_REQUIRE(aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v) && (!p_bf16 || (((uintptr_t)p_bf16) & 7) == 0), "pero_adam_step: alignment");
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  hipLaunchKernelGGL(adam_k, dim3(grid_for(n, 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16raw*)p_bf16, (long long)n,
+                     (float)((double)lr / bc1), beta1, beta2, (float)(1.0 - (double)beta1), (float)(1.0 - (double)beta2), eps, (float)(1.0 / sqrt(bc2)), grad_scale);
+  PERO_CHECK_LAUNCH("pero_adam_step");
+  return PERO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// row gather / scatter-add (boolean-mask row selections of the losses; d % 8 == 0 fast path not needed:
+// one wave per row, scalar elements, rows are >= 96 bytes)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void gather_rows_k(const T* src, const int64_t* index, T* dst, long long n_idx, long long n_out, int d) {
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n_out) return;
+  const int lane = threadIdx.x & 63;
+  if (row < n_idx) {
+    const T* s = src + index[row] * d;
+    for (int c = lane; c < d; c += 64) dst[row * d + c] = s[c];
+  } else {
+    for (int c = lane; c < d; c += 64) Elem<T>::st(dst + row * d + c, 0.f);
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void scatter_add_rows_k(const T* src, const int64_t* index, T* dst, long long n_idx, int d) {
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n_idx) return;
+  const int lane = threadIdx.x & 63;
+  T* o = dst + index[row] * d;
+  for (int c = lane; c < d; c += 64) Elem<T>::st(o + c, Elem<T>::ld(o + c) + Elem<T>::ld(src + row * d + c));
+}
+extern "C" int pero_gather_rows(const void* src, const int64_t* index, void* dst, int64_t n_idx, int64_t n_rows_out, int64_t d,
+                                int dtype, void* stream) {
+  PERO_REQUIRE(src && dst && (index || n_idx == 0) && n_rows_out >= n_idx && n_rows_out > 0 && d > 0, "pero_gather_rows: bad arguments");
+  dim3 grid((unsigned)((n_rows_out + 3) / 4)), block(256);
+  if (dtype == PERO_F32) hipLaunchKernelGGL((gather_rows_k<float>), grid, block, 0, (hipStream_t)stream, (const float*)src, index, (float*)dst, (long long)n_idx, (long long)n_rows_out, (int)d);
+  else if (dtype == PERO_BF16) hipLaunchKernelGGL((gather_rows_k<bf16raw>), grid, block, 0, (hipStream_t)stream, (const bf16raw*)src, index, (bf16raw*)dst, (long long)n_idx, (long long)n_rows_out, (int)d);
+  else PERO_REQUIRE(false, "pero_gather_rows: bad dtype");
+  PERO_CHECK_LAUNCH("pero_gather_rows");
+  return PERO_OK;
+}
+extern "C" int pero_scatter_add_rows(const void* src, const int64_t* index, void* dst, int64_t n_idx, int64_t d, int dtype, void* stream) {
+  PERO_REQUIRE(src && dst && index && n_idx > 0 && d > 0, "pero_scatter_add_rows: bad arguments");
+  dim3 grid((unsigned)((n_idx + 3) / 4)), block(256);
+  if (dtype == PERO_F32) hipLaunchKernelGGL((scatter_add_rows_k<float>), grid, block, 0, (hipStream_t)stream, (const float*)src, index, (float*)dst, (long long)n_idx, (int)d);
+  else if (dtype == PERO_BF16) hipLaunchKernelGGL((scatter_add_rows_k<bf16raw>), grid, block, 0, (hipStream_t)stream, (const bf16raw*)src, index, (bf16raw*)dst, (long long)n_idx, (int)d);
+  else PERO_REQUIRE(false, "pero_scatter_add_rows: bad dtype");
+  PERO_CHECK_LAUNCH("pero_scatter_add_rows");
+  return PERO_OK;
+}

@@ -1,0 +1,365 @@
+// Row-wise HBM-bound kernels: LayerNorm (+positional encoding) fwd/bwd, softmax fwd/bwd, masked
+// cross entropy, column sums.  One 64-lane wave per row (shuffle reductions, no LDS for the row
+// statistics), 16-byte global accesses, f32 statistics whatever the storage dtype.
+#include "common.hpp"
+
+template <typename T> __device__ __forceinline__ void load8(const T* p, float (&v)[8]);
+template <> __device__ __forceinline__ void load8<float>(const float* p, float (&v)[8]) {
+  const f4v a = *(const f4v*)p, b = *(const f4v*)(p + 4);
+  v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+}
+template <> __device__ __forceinline__ void load8<bf16raw>(const bf16raw* p, float (&v)[8]) {
+  const uint4 r = *(const uint4*)p;
+  const unsigned w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+  for (int e = 0; e < 4; e++) { v[2 * e] = __uint_as_float(w[e] << 16); v[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u); }
+}
+template <typename T> __device__ __forceinline__ void store8(T* p, const float (&v)[8]);
+template <> __device__ __forceinline__ void store8<float>(float* p, const float (&v)[8]) {
+  *(f4v*)p = (f4v){v[0], v[1], v[2], v[3]};
+  *(f4v*)(p + 4) = (f4v){v[4], v[5], v[6], v[7]};
+}
+template <> __device__ __forceinline__ void store8<bf16raw>(bf16raw* p, const float (&v)[8]) {
+  uint4 o;
+  o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]); o.z = pack2bf(v[4], v[5]); o.w = pack2bf(v[6], v[7]);
+  *(uint4*)p = o;
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm forward.  d % 8 == 0, d <= 512 * NCH.  4 waves per block, one row per wave.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void layernorm_fwd_k(const T* x, const float* gamma, const float* beta, const float* pe,
+                                                       const int64_t* offsets, T* y, float* mean, float* rstd,
+                                                       long long rows, int d, long long S, float eps) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float v[NCH][8];
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; c++) {
+    const int col = (c * 64 + lane) * 8;
+    if (col < d) {
+      load8<T>(x + row * d + col, v[c]);
+#pragma unroll
+      for (int e = 0; e < 8; e++) s += v[c][e];
+    }
+  }
+  const float mu = wave_sum(s) / (float)d;
+  float q = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; c++) {
+    const int col = (c * 64 + lane) * 8;
+    if (col < d) {
+#pragma unroll
+      for (int e = 0; e < 8; e++) { const float t = v[c][e] - mu; q += t * t; }
+    }
+  }
+  const float rs = 1.0f / sqrtf(wave_sum(q) / (float)d + eps);
+  if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+  const float* perow = nullptr;
+  if (pe) {
+    const long long line = row / S, pos = row % S;
+    perow = pe + ((offsets ? offsets[line] : 0) + pos) * d;
+  }
+#pragma unroll
+  for (int c = 0; c < NCH; c++) {
+    const int col = (c * 64 + lane) * 8;
+    if (col < d) {
+      float g[8], b[8], o[8];
+      load8<float>(gamma + col, g);
+      load8<float>(beta + col, b);
+#pragma unroll
+      for (int e = 0; e < 8; e++) o[e] = (v[c][e] - mu) * rs * g[e] + b[e];
+      if (perow) {
+        float pp[8];
+        load8<float>(perow + col, pp);
+#pragma unroll
+        for (int e = 0; e < 8; e++) o[e] += pp[e];
+      }
+      store8<T>(y + row * d + col, o);
+    }
+  }
+}
+
+// LayerNorm backward: dx per row; dgamma / dbeta / column sums of dx accumulated per lane over the rows
+// a wave visits, combined across the block's 4 waves through LDS, then one f32 atomic per column.
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void layernorm_bwd_k(const T* dy, const T* x, const float* mean, const float* rstd,
+                                                       const float* gamma, T* dx, float* dgamma, float* dbeta, float* dxsum,
+                                                       long long rows, int d) {
+  __shared__ float red[4][NCH * 512];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float ag[NCH][8], ab[NCH][8], ax[NCH][8], g[NCH][8];
+#pragma unroll
+  for (int c = 0; c < NCH; c++) {
+    const int col = (c * 64 + lane) * 8;
+#pragma unroll
+    for (int e = 0; e < 8; e++) { ag[c][e] = 0.f; ab[c][e] = 0.f; ax[c][e] = 0.f; g[c][e] = 0.f; }
+    if (col < d) load8<float>(gamma + col, g[c]);
+  }
+  for (long long row = (long long)blockIdx.x * 4 + wave; row < rows; row += (long long)gridDim.x * 4) {
+    const float mu = mean[row], rs = rstd[row];
+    float xh[NCH][8], gy[NCH][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+      const int col = (c * 64 + lane) * 8;
+      if (col < d) {
+        float xv[8], dv[8];
+        load8<T>(x + row * d + col, xv);
+        load8<T>(dy + row * d + col, dv);
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          xh[c][e] = (xv[e] - mu) * rs;
+          gy[c][e] = dv[e] * g[c][e];
+          s1 += gy[c][e];
+          s2 += gy[c][e] * xh[c][e];
+          ag[c][e] += dv[e] * xh[c][e];
+          ab[c][e] += dv[e];
+        }
+      }
+    }
+    const float c1 = wave_sum(s1) / (float)d, c2 = wave_sum(s2) / (float)d;
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+      const int col = (c * 64 + lane) * 8;
+      if (col < d) {
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) { o[e] = rs * (gy[c][e] - c1 - xh[c][e] * c2); ax[c][e] += o[e]; }
+        store8<T>(dx + row * d + col, o);
+      }
+    }
+  }
+  // three rounds (dgamma, dbeta, dxsum) through one 4 x d LDS slab
+#pragma unroll
+  for (int which = 0; which < 3; which++) {
+    if (which == 2 && !dxsum) break;
+#pragma unroll
+    for (int c = 0; c < NCH; c++)
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        const int col = (c * 64 + lane) * 8 + e;
+        red[wave][col] = which == 0 ? ag[c][e] : (which == 1 ? ab[c][e] : ax[c][e]);
+      }
+    __syncthreads();
+    float* dst = which == 0 ? dgamma : (which == 1 ? dbeta : dxsum);
+    for (int col = threadIdx.x; col < d; col += 256)
+      atomicAdd(dst + col, (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]));
+    __syncthreads();
+  }
+}
+
+template <typename T>
+static int ln_dispatch_fwd(const void* x, const float* gamma, const float* beta, const float* pe, const int64_t* offsets,
+                           void* y, float* mean, float* rstd, int64_t rows, int64_t d, int64_t S, float eps, hipStream_t st) {
+  dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  const int nch = (int)((d + 511) / 512);
+#define LN_F(N_) hipLaunchKernelGGL((layernorm_fwd_k<T, N_>), grid, block, 0, st, (const T*)x, gamma, beta, pe, offsets, (T*)y, mean, rstd, (long long)rows, (int)d, (long long)S, eps)
+  if (nch == 1) LN_F(1); else if (nch == 2) LN_F(2); else if (nch <= 4) LN_F(4); else LN_F(8);
+#undef LN_F
+  return 0;
+}
+template <typename T>
+static int ln_dispatch_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma, void* dx,
+                           float* dgamma, float* dbeta, float* dxsum, int64_t rows, int64_t d, hipStream_t st) {
+  long long blocks = (rows + 3) / 4;
+  if (blocks > 1024) blocks = 1024;
+  dim3 grid((unsigned)blocks), block(256);
+  const int nch = (int)((d + 511) / 512);
+#define LN_B(N_) hipLaunchKernelGGL((layernorm_bwd_k<T, N_>), grid, block, 0, st, (const T*)dy, (const T*)x, mean, rstd, gamma, (T*)dx, dgamma, dbeta, dxsum, (long long)rows, (int)d)
+  if (nch == 1) LN_B(1); else if (nch == 2) LN_B(2); else LN_B(4);
+#undef LN_B
+  return 0;
+}
+
+extern "C" int pero_layernorm_fwd(const void* x, const float* gamma, const float* beta, const float* pe, const int64_t* offsets,
+                                  void* y, float* mean, float* rstd, int64_t rows, int64_t d, int64_t S, float eps, int dtype,
+                                  void* stream) {
+  PERO_REQUIRE(x && gamma && beta && y && mean && rstd, "pero_layernorm_fwd: null pointer");
+  PERO_REQUIRE(rows > 0 && d > 0 && d % 8 == 0 && d <= 4096, "pero_layernorm_fwd: need d %% 8 == 0 and d <= 4096 (d=%lld)", (long long)d);
+  PERO_REQUIRE(!pe || S > 0, "pero_layernorm_fwd: S must be > 0 with a positional table");
+  PERO_REQUIRE(aligned16(x) && aligned16(y) && aligned16(gamma) && aligned16(beta) && (!pe || aligned16(pe)), "pero_layernorm_fwd: 16-byte alignment");
+  if (dtype == PERO_F32) ln_dispatch_fwd<float>(x, gamma, beta, pe, offsets, y, mean, rstd, rows, d, S, eps, (hipStream_t)stream);
+  else if (dtype == PERO_BF16) ln_dispatch_fwd<bf16raw>(x, gamma, beta, pe, offsets, y, mean, rstd, rows, d, S, eps, (hipStream_t)stream);
+  else PERO_REQUIRE(false, "pero_layernorm_fwd: bad dtype");
+  PERO_CHECK_LAUNCH("pero_layernorm_fwd");
+  return PERO_OK;
+}
+
+extern "C" int pero_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                                  void* dx, float* dgamma, float* dbeta, float* dxsum, int64_t rows, int64_t d, int dtype,
+                                  void* stream) {
+  PERO_REQUIRE(dy && x && mean && rstd && gamma && dx && dgamma && dbeta, "pero_layernorm_bwd: null pointer");
+  PERO_REQUIRE(rows > 0 && d > 0 && d % 8 == 0 && d <= 2048, "pero_layernorm_bwd: need d %% 8 == 0 and d <= 2048 (d=%lld)", (long long)d);
+  PERO_REQUIRE(aligned16(dy) && aligned16(x) && aligned16(dx) && aligned16(gamma), "pero_layernorm_bwd: 16-byte alignment");
+  if (dtype == PERO_F32) ln_dispatch_bwd<float>(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, dxsum, rows, d, (hipStream_t)stream);
+  else if (dtype == PERO_BF16) ln_dispatch_bwd<bf16raw>(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, dxsum, rows, d, (hipStream_t)stream);
+  else PERO_REQUIRE(false, "pero_layernorm_bwd: bad dtype");
+  PERO_CHECK_LAUNCH("pero_layernorm_bwd");
+  return PERO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// softmax (attention probabilities): scores f32 -> p (T); one wave per row
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_fwd_k(const float* s, T* p, long long rows, int cols, float scale) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* sr = s + row * cols;
+  float mx = -INFINITY;
+  for (int c = lane; c < cols; c += 64) mx = fmaxf(mx, sr[c] * scale);
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int c = lane; c < cols; c += 64) sum += expf(sr[c] * scale - mx);
+  sum = wave_sum(sum);
+  const float inv = 1.0f / sum;
+  for (int c = lane; c < cols; c += 64) Elem<T>::st(p + row * cols + c, expf(sr[c] * scale - mx) * inv);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_bwd_k(const T* p, const float* dp, T* ds, long long rows, int cols, float scale) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float dot = 0.f;
+  for (int c = lane; c < cols; c += 64) dot += Elem<T>::ld(p + row * cols + c) * dp[row * cols + c];
+  dot = wave_sum(dot);
+  for (int c = lane; c < cols; c += 64)
+    Elem<T>::st(ds + row * cols + c, scale * Elem<T>::ld(p + row * cols + c) * (dp[row * cols + c] - dot));
+}
+extern "C" int pero_softmax_fwd(const float* s, void* p, int64_t rows, int64_t cols, float scale, int dtype, void* stream) {
+  PERO_REQUIRE(s && p && rows > 0 && cols > 0, "pero_softmax_fwd: bad arguments");
+  dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  if (dtype == PERO_F32) hipLaunchKernelGGL((softmax_fwd_k<float>), grid, block, 0, (hipStream_t)stream, s, (float*)p, (long long)rows, (int)cols, scale);
+  else if (dtype == PERO_BF16) hipLaunchKernelGGL((softmax_fwd_k<bf16raw>), grid, block, 0, (hipStream_t)stream, s, (bf16raw*)p, (long long)rows, (int)cols, scale);
+  else PERO_REQUIRE(false, "pero_softmax_fwd: bad dtype");
+  PERO_CHECK_LAUNCH("pero_softmax_fwd");
+  return PERO_OK;
+}
+extern "C" int pero_softmax_bwd(const void* p, const float* dp, void* ds, int64_t rows, int64_t cols, float scale, int dtype, void* stream) {
+  PERO_REQUIRE(p && dp && ds && rows > 0 && cols > 0, "pero_softmax_bwd: bad arguments");
+  dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  if (dtype == PERO_F32) hipLaunchKernelGGL((softmax_bwd_k<float>), grid, block, 0, (hipStream_t)stream, (const float*)p, dp, (float*)ds, (long long)rows, (int)cols, scale);
+  else if (dtype == PERO_BF16) hipLaunchKernelGGL((softmax_bwd_k<bf16raw>), grid, block, 0, (hipStream_t)stream, (const bf16raw*)p, dp, (bf16raw*)ds, (long long)rows, (int)cols, scale);
+  else PERO_REQUIRE(false, "pero_softmax_bwd: bad dtype");
+  PERO_CHECK_LAUNCH("pero_softmax_bwd");
+  return PERO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// masked cross entropy.  work[0..rows) = per-row loss, work[rows+0] = n_masked, work[rows+1] = n_unmasked
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ce_count_k(const int64_t* labels, const int64_t* mask, float* work, long long rows) {
+  __shared__ int sm[2][4];
+  int nm = 0, nu = 0;
+  for (long long r = threadIdx.x; r < rows; r += 256) {
+    if (mask[r] == 1) nm++;
+    else if (mask[r] == 0 && labels[r] >= 0) nu++;
+  }
+  nm = (int)wave_sum((float)nm);  // exact: counts < 2^24
+  nu = (int)wave_sum((float)nu);
+  if ((threadIdx.x & 63) == 0) { sm[0][threadIdx.x >> 6] = nm; sm[1][threadIdx.x >> 6] = nu; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    work[rows] = (float)(sm[0][0] + sm[0][1] + sm[0][2] + sm[0][3]);
+    work[rows + 1] = (float)(sm[1][0] + sm[1][1] + sm[1][2] + sm[1][3]);
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void ce_rows_k(const T* logits, const int64_t* labels, const int64_t* mask, float uw,
+                                                 T* dlogits, float* work, long long rows, int V) {
+  __shared__ float red[4];
+  const long long row = blockIdx.x;
+  const int tid = threadIdx.x;
+  const long long lab = labels[row];
+  const long long mk = mask[row];
+  float w = 0.f;
+  if (mk == 1) w = 1.0f / work[rows];
+  else if (mk == 0 && lab >= 0 && uw >= 0.f) w = uw / work[rows + 1];
+  const bool active = (mk == 1) || (mk == 0 && lab >= 0 && uw >= 0.f);
+  if (!active) {
+    if (tid == 0) work[row] = 0.f;
+    if (dlogits) for (int c = tid; c < V; c += 256) Elem<T>::st(dlogits + row * V + c, 0.f);
+    return;
+  }
+  const T* lr = logits + row * V;
+  float mx = -INFINITY;
+  for (int c = tid; c < V; c += 256) mx = fmaxf(mx, Elem<T>::ld(lr + c));
+  mx = wave_max(mx);
+  if ((tid & 63) == 0) red[tid >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float sum = 0.f;
+  for (int c = tid; c < V; c += 256) sum += expf(Elem<T>::ld(lr + c) - mx);
+  sum = wave_sum(sum);
+  if ((tid & 63) == 0) red[tid >> 6] = sum;
+  __syncthreads();
+  sum = (red[0] + red[1]) + (red[2] + red[3]);
+  const float lse = logf(sum) + mx;
+  if (tid == 0) work[row] = lse - Elem<T>::ld(lr + lab);
+  if (dlogits) {
+    const float inv = 1.0f / sum;
+    for (int c = tid; c < V; c += 256) {
+      float g = expf(Elem<T>::ld(lr + c) - mx) * inv;
+      if (c == lab) g -= 1.0f;
+      Elem<T>::st(dlogits + row * V + c, g * w);
+    }
+  }
+}
+__global__ __launch_bounds__(256) void ce_final_k(const int64_t* labels, const int64_t* mask, float uw, const float* work,
+                                                  float* loss, long long rows) {
+  __shared__ float sm[2][4];
+  float a = 0.f, b = 0.f;  // fixed summation order: deterministic
+  for (long long r = threadIdx.x; r < rows; r += 256) {
+    if (mask[r] == 1) a += work[r];
+    else if (mask[r] == 0 && labels[r] >= 0) b += work[r];
+  }
+  a = wave_sum(a); b = wave_sum(b);
+  if ((threadIdx.x & 63) == 0) { sm[0][threadIdx.x >> 6] = a; sm[1][threadIdx.x >> 6] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float l = ((sm[0][0] + sm[0][1]) + (sm[0][2] + sm[0][3])) / work[rows];
+    if (uw >= 0.f) l += uw * (((sm[1][0] + sm[1][1]) + (sm[1][2] + sm[1][3])) / work[rows + 1]);
+    loss[0] = l;
+  }
+}
+extern "C" int pero_masked_ce(const void* logits, const int64_t* labels, const int64_t* mask, float unmasked_weight,
+                              float* loss_out, void* dlogits, float* work, int64_t rows, int64_t V, int dtype, void* stream) {
+  PERO_REQUIRE(logits && labels && mask && loss_out && work, "pero_masked_ce: null pointer");
+  PERO_REQUIRE(rows > 0 && V > 0 && rows < 16777216, "pero_masked_ce: bad sizes");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(ce_count_k, dim3(1), dim3(256), 0, st, labels, mask, work, (long long)rows);
+  if (dtype == PERO_F32) hipLaunchKernelGGL((ce_rows_k<float>), dim3((unsigned)rows), dim3(256), 0, st, (const float*)logits, labels, mask, unmasked_weight, (float*)dlogits, work, (long long)rows, (int)V);
+  else if (dtype == PERO_BF16) hipLaunchKernelGGL((ce_rows_k<bf16raw>), dim3((unsigned)rows), dim3(256), 0, st, (const bf16raw*)logits, labels, mask, unmasked_weight, (bf16raw*)dlogits, work, (long long)rows, (int)V);
+  else PERO_REQUIRE(false, "pero_masked_ce: bad dtype");
+  hipLaunchKernelGGL(ce_final_k, dim3(1), dim3(256), 0, st, labels, mask, unmasked_weight, work, loss_out, (long long)rows);
+  PERO_CHECK_LAUNCH("pero_masked_ce");
+  return PERO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// column sums: out[n] += sum_m x[m][n]
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_k(const T* x, float* out, long long rows, long long cols, long long ld) {
+  const long long col = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (col >= cols) return;
+  float s = 0.f;
+  for (long long r = blockIdx.y; r < rows; r += gridDim.y) s += Elem<T>::ld(x + r * ld + col);
+  atomicAdd(out + col, s);
+}
+extern "C" int pero_colsum(const void* x, float* out, int64_t rows, int64_t cols, int64_t ld, int dtype, void* stream) {
+  PERO_REQUIRE(x && out && rows > 0 && cols > 0 && ld >= cols, "pero_colsum: bad arguments");
+  long long gy = rows < 128 ? rows : 128;
+  dim3 grid((unsigned)((cols + 255) / 256), (unsigned)gy), block(256);
+  if (dtype == PERO_F32) hipLaunchKernelGGL((colsum_k<float>), grid, block, 0, (hipStream_t)stream, (const float*)x, out, (long long)rows, (long long)cols, (long long)ld);
+  else if (dtype == PERO_BF16) hipLaunchKernelGGL((colsum_k<bf16raw>), grid, block, 0, (hipStream_t)stream, (const bf16raw*)x, out, (long long)rows, (long long)cols, (long long)ld);
+  else PERO_REQUIRE(false, "pero_colsum: bad dtype");
+  PERO_CHECK_LAUNCH("pero_colsum");
+  return PERO_OK;
+}

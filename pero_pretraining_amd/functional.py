@@ -1,0 +1,167 @@
+"""Forward / backward of the transformer hot path, sequenced on the host as HIP kernel launches.
+
+Token layout: every activation is a row-major (N*S, d) matrix of token rows (line-major), which is
+what the reference reaches after its `n d s -> s n d` / `s n d -> n d s` transposes
+(models/transformers.py:82-89) - those are pure layout and vanish here.
+
+Attention (round 1): per (line, head) batched GEMMs on the packed qkv tensor + a row softmax kernel
+(scores kept in f32), i.e. the unfused form of torch SDPA.  Every product of the backward pass is the
+same GEMM kernel with a different operand-layout flag; weight gradients are accumulated straight into
+the parameters' `.grad` buffers with f32 atomics (split-K over the token dimension).
+"""
+import math
+
+import torch
+
+from . import lowp, ops
+from ._lib import GEMM_ATOMIC, GEMM_TRANS_A, GEMM_TRANS_B
+
+LN_EPS = 1e-5
+
+
+def _ksplit(rows, out_elems):
+    """Split the token (reduction) dimension of a weight-gradient GEMM so that the grid fills 256 CUs."""
+    tiles = max(1, out_elems // (128 * 128))
+    want = max(1, 512 // tiles)
+    return int(max(1, min(want, rows // 512 if rows >= 512 else 1)))
+
+
+def ensure_grad(p):
+    """Parameter gradient buffer the kernels accumulate into (zero-filled when freshly created)."""
+    if p.grad is None:
+        p.grad = torch.zeros_like(p, memory_format=torch.contiguous_format)
+    return p.grad
+
+
+def linear_fwd(x, w, b, dtype, residual=None, relu=False, out_dtype=None):
+    return ops.gemm(x, lowp.weight(w, dtype), bias=None if b is None else b.detach(), residual=residual, relu=relu,
+                    out_dtype=out_dtype)
+
+
+def linear_bwd(dy, x, w, b, dtype, need_dx=True, gate=None, residual=None, bias_grad_done=False):
+    """dy (M,N), x (M,K), w (N,K).  Accumulates dW (+db) into .grad; returns dx = dy @ W (+residual)(*gate>0)."""
+    if w.requires_grad:
+        gw = ensure_grad(w)
+        ops.gemm(dy, x, out=gw.view(w.shape[0], -1), trans_a=True, trans_b=True, atomic=True,
+                 k_split=_ksplit(dy.shape[0], w.numel()))
+    if b is not None and b.requires_grad and not bias_grad_done:
+        ops.colsum(dy, ensure_grad(b))
+    if not need_dx:
+        return None
+    return ops.gemm(dy, lowp.weight(w, dtype).view(w.shape[0], -1), trans_b=True, residual=residual, gate=gate)
+
+
+# ---------------------------------------------------------------------------------------------
+# attention on the packed qkv tensor
+# ---------------------------------------------------------------------------------------------
+def attention_fwd(qkv, n, s, h, need_p=True):
+    d = qkv.shape[1] // 3
+    hd = d // h
+    scores = torch.empty((n * h, s, s), device=qkv.device, dtype=torch.float32)
+    ops.gemm_raw(qkv, qkv[:, d:], scores, s, s, hd, 3 * d, 3 * d, s, batch=n * h, batch_inner=h,
+                 sA=(s * 3 * d, hd), sB=(s * 3 * d, hd), sC=(h * s * s, s * s))
+    p = ops.softmax_fwd(scores, 1.0 / math.sqrt(hd), qkv.dtype)
+    out = torch.empty((n * s, d), device=qkv.device, dtype=qkv.dtype)
+    ops.gemm_raw(p, qkv[:, 2 * d:], out, s, hd, s, s, 3 * d, d, batch=n * h, batch_inner=h,
+                 sA=(h * s * s, s * s), sB=(s * 3 * d, hd), sC=(s * d, hd), flags=GEMM_TRANS_B)
+    return out, p
+
+
+def attention_bwd(qkv, p, dout, n, s, h):
+    d = qkv.shape[1] // 3
+    hd = d // h
+    dqkv = torch.empty_like(qkv)
+    bq = dict(batch=n * h, batch_inner=h)
+    sP, sQ, sO = (h * s * s, s * s), (s * 3 * d, hd), (s * d, hd)
+    # dV = P^T dO
+    ops.gemm_raw(p, dout, dqkv[:, 2 * d:], s, hd, s, s, d, 3 * d, sA=sP, sB=sO, sC=sQ,
+                 flags=GEMM_TRANS_A | GEMM_TRANS_B, **bq)
+    # dP = dO V^T  (f32)
+    dp = torch.empty((n * h, s, s), device=qkv.device, dtype=torch.float32)
+    ops.gemm_raw(dout, qkv[:, 2 * d:], dp, s, s, hd, d, 3 * d, s, sA=sO, sB=sQ, sC=sP, **bq)
+    ds = ops.softmax_bwd(p, dp, 1.0 / math.sqrt(hd))
+    # dQ = dS K ; dK = dS^T Q
+    ops.gemm_raw(ds, qkv[:, d:], dqkv, s, hd, s, s, 3 * d, 3 * d, sA=sP, sB=sQ, sC=sQ, flags=GEMM_TRANS_B, **bq)
+    ops.gemm_raw(ds, qkv, dqkv[:, d:], s, hd, s, s, 3 * d, 3 * d, sA=sP, sB=sQ, sC=sQ,
+                 flags=GEMM_TRANS_A | GEMM_TRANS_B, **bq)
+    return dqkv
+
+
+# ---------------------------------------------------------------------------------------------
+# one post-norm encoder layer (torch.nn.TransformerEncoderLayer semantics, models/transformers.py:36-43)
+# ---------------------------------------------------------------------------------------------
+def layer_fwd(t, L, n, s, h, dtype, save):
+    at = L.self_attn
+    qkv = linear_fwd(t, at.in_proj_weight, at.in_proj_bias, dtype)
+    a, p = attention_fwd(qkv, n, s, h)
+    y1 = linear_fwd(a, at.out_proj.weight, at.out_proj.bias, dtype, residual=t)
+    t1, mean1, rstd1 = ops.layernorm_fwd(y1, L.norm1.weight.detach(), L.norm1.bias.detach(), L.norm1.eps)
+    hdn = linear_fwd(t1, L.linear1.weight, L.linear1.bias, dtype, relu=True)
+    y2 = linear_fwd(hdn, L.linear2.weight, L.linear2.bias, dtype, residual=t1)
+    t2, mean2, rstd2 = ops.layernorm_fwd(y2, L.norm2.weight.detach(), L.norm2.bias.detach(), L.norm2.eps)
+    saved = (t, qkv, p, a, y1, mean1, rstd1, t1, hdn, y2, mean2, rstd2) if save else None
+    return t2, saved
+
+
+def layer_bwd(dt2, L, saved, n, s, h, dtype):
+    t, qkv, p, a, y1, mean1, rstd1, t1, hdn, y2, mean2, rstd2 = saved
+    at = L.self_attn
+    # LN2 (its dx column sums are linear2's bias gradient)
+    dy2 = ops.layernorm_bwd(dt2, y2, mean2, rstd2, L.norm2.weight.detach(), ensure_grad(L.norm2.weight),
+                            ensure_grad(L.norm2.bias), ensure_grad(L.linear2.bias))
+    dpre1 = linear_bwd(dy2, hdn, L.linear2.weight, L.linear2.bias, dtype, gate=hdn, bias_grad_done=True)
+    dt1 = linear_bwd(dpre1, t1, L.linear1.weight, L.linear1.bias, dtype, residual=dy2)
+    dy1 = ops.layernorm_bwd(dt1, y1, mean1, rstd1, L.norm1.weight.detach(), ensure_grad(L.norm1.weight),
+                            ensure_grad(L.norm1.bias), ensure_grad(at.out_proj.bias))
+    da = linear_bwd(dy1, a, at.out_proj.weight, at.out_proj.bias, dtype, bias_grad_done=True)
+    dqkv = attention_bwd(qkv, p, da, n, s, h)
+    return linear_bwd(dqkv, t, at.in_proj_weight, at.in_proj_bias, dtype, residual=dy1)
+
+
+# ---------------------------------------------------------------------------------------------
+# whole backbone: front end + L layers
+# ---------------------------------------------------------------------------------------------
+def backbone_fwd(mod, x, mask, offsets, dtype, save):
+    """x: uint8 (N,H,W,C) line images, or float32 (N,C,H,W) (the reference's model input).
+    Returns (tokens (N*S, d) in `dtype`, saved activations or None)."""
+    P = mod.patch_size[1]
+    tile = mod.mask_tile_device(x.device)
+    if mask is not None:
+        mask = torch.as_tensor(mask).to(device=x.device, dtype=torch.int64).contiguous()
+    if x.dtype == torch.uint8:
+        n, _, w, _ = x.shape
+        a0 = ops.patches_from_u8(x.contiguous(), mask, tile, P, dtype)
+    else:
+        n, _, _, w = x.shape
+        xc = x.detach()
+        if xc.dtype != torch.float32 or not xc.is_contiguous():
+            xc = xc.float().contiguous()
+        a0 = ops.patches_from_f32(xc, mask, tile, P, dtype)
+    s = w // P
+    d = mod.model_dim
+    y0 = ops.gemm(a0, lowp.weight(mod.conv_layer.weight, dtype).view(d, -1), bias=mod.conv_layer.bias.detach())
+    pe = mod.position_model.pe_table(x.device)
+    t, mean0, rstd0 = ops.layernorm_fwd(y0, mod.intermediate_norm.weight.detach(), mod.intermediate_norm.bias.detach(),
+                                        mod.intermediate_norm.eps, pe=pe, offsets=offsets, S=s)
+    layers = []
+    for L in mod.encoder_layers.layers:
+        t, sv = layer_fwd(t, L, n, s, mod.num_heads, dtype, save)
+        layers.append(sv)
+    saved = (a0, y0, mean0, rstd0, layers, n, s) if save else None
+    return t, saved
+
+
+def backbone_bwd(mod, saved, dt, dtype, on_layer_done=None):
+    a0, y0, mean0, rstd0, layers, n, s = saved
+    nl = len(layers)
+    for i in range(nl - 1, -1, -1):
+        dt = layer_bwd(dt, mod.encoder_layers.layers[i], layers[i], n, s, mod.num_heads, dtype)
+        layers[i] = None
+        if on_layer_done is not None:
+            on_layer_done(i)
+    nrm = mod.intermediate_norm
+    dy0 = ops.layernorm_bwd(dt, y0, mean0, rstd0, nrm.weight.detach(), ensure_grad(nrm.weight), ensure_grad(nrm.bias),
+                            ensure_grad(mod.conv_layer.bias))
+    linear_bwd(dy0, a0, mod.conv_layer.weight, mod.conv_layer.bias, dtype, need_dx=False, bias_grad_done=True)
+    if on_layer_done is not None:
+        on_layer_done(-1)

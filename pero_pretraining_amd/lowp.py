@@ -1,0 +1,49 @@
+"""bf16 copies of f32 master parameters for the bf16 MFMA path.
+
+`get(p)` returns a bf16 tensor mirroring parameter `p`; it is re-cast (one HIP cast kernel) whenever
+the parameter changed (`_version` / storage) since the copy was made.  The fused optimizer
+(`optim.FusedAdam`) writes the bf16 copy of the whole flat parameter buffer inside its own kernel and
+registers the fresh views through `put`, so a training step issues no separate cast.
+"""
+import torch
+
+from . import ops
+
+_cache = {}
+
+
+def _key(p):
+    return (p._version, p.data_ptr(), tuple(p.shape))
+
+
+def get(p):
+    ent = _cache.get(id(p))
+    k = _key(p)
+    if ent is not None and ent[0] == k:
+        return ent[1]
+    if ent is not None and ent[2]:      # view into a flat buffer owned by the optimizer: refresh in place
+        dst = ent[1]
+    else:
+        dst = torch.empty(p.shape, device=p.device, dtype=torch.bfloat16)
+    src = p.detach()
+    if src.numel() % 8 == 0 and src.is_contiguous() and src.data_ptr() % 16 == 0 and dst.data_ptr() % 16 == 0:
+        ops.cast_to_bf16(src, dst)
+    else:  # tiny / unaligned tensors: pad through a scratch buffer
+        n = src.numel()
+        pad = torch.zeros(((n + 7) // 8) * 8, device=p.device, dtype=torch.float32)
+        pad[:n] = src.reshape(-1)
+        tmp = torch.empty(pad.numel(), device=p.device, dtype=torch.bfloat16)
+        ops.cast_to_bf16(pad, tmp)
+        dst.reshape(-1).copy_(tmp[:n])
+    _cache[id(p)] = (k, dst, ent[2] if ent is not None else False)
+    return dst
+
+
+def put(p, lp_view):
+    """Register `lp_view` (bf16, already holding the current value of p) as p's copy."""
+    _cache[id(p)] = (_key(p), lp_view, True)
+
+
+def weight(p, dtype):
+    """Parameter tensor in the requested compute dtype."""
+    return p.detach() if dtype == torch.float32 else get(p)

@@ -1,0 +1,183 @@
+"""Tensor-level wrappers over the C ABI (libpero_hip.so).  PyTorch supplies device memory and the
+current HIP stream; all arithmetic happens in the hand-written kernels.  No CPU fallback."""
+import torch
+
+from . import _lib
+from ._lib import (GEMM_ACCUM, GEMM_ATOMIC, GEMM_FORCE_GENERIC, GEMM_RELU, GEMM_TRANS_A, GEMM_TRANS_B,
+                   PERO_BF16, PERO_F32, call)
+
+
+def dt(t_or_dtype):
+    d = t_or_dtype.dtype if isinstance(t_or_dtype, torch.Tensor) else t_or_dtype
+    if d == torch.float32:
+        return PERO_F32
+    if d == torch.bfloat16:
+        return PERO_BF16
+    raise TypeError(f"unsupported dtype {d}")
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _req_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.PeroHipError("pero_pretraining_amd ops need CUDA/HIP tensors: the HIP kernels are the only "
+                                    "implementation (no CPU fallback)")
+
+
+def gemm_raw(A, B, C, M, N, K, lda, ldb, ldc, *, bias=None, residual=None, gate=None, ldr=0, ldg=0, batch=1,
+             batch_inner=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), alpha=1.0, flags=0, k_split=1, in_dtype=None,
+             out_dtype=None):
+    """Direct pero_gemm call; A/B/C may be tensors (pointer taken at storage offset) or raw ints."""
+    _req_cuda(A, B, C)
+    call("pero_gemm", ptr(A), ptr(B), ptr(C), ptr(bias), ptr(residual), ptr(gate), M, N, K, lda, ldb, ldc, ldr, ldg,
+         batch, batch_inner, sA[0], sA[1], sB[0], sB[1], sC[0], sC[1], float(alpha), int(flags), int(k_split),
+         dt(A) if in_dtype is None else in_dtype, dt(C) if out_dtype is None else out_dtype, stream())
+
+
+def gemm(a, b, out=None, *, bias=None, residual=None, gate=None, trans_a=False, trans_b=False, relu=False,
+         alpha=1.0, out_dtype=None, atomic=False, accum=False, k_split=1, force_generic=False):
+    """out[M,N] = alpha * op(a) @ op(b)^T ...   a: [M,K] ([K,M] if trans_a); b: [N,K] ([K,N] if trans_b).
+    Row-strided 2-D views are fine (unit stride in the last dim)."""
+    assert a.dim() == 2 and b.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1
+    M, K = (a.shape[1], a.shape[0]) if trans_a else a.shape
+    N, Kb = (b.shape[1], b.shape[0]) if trans_b else b.shape
+    assert K == Kb, (a.shape, b.shape, trans_a, trans_b)
+    if out is None:
+        out = torch.empty((M, N), device=a.device, dtype=out_dtype or a.dtype)
+    assert out.shape == (M, N) and out.stride(1) == 1
+    flags = (GEMM_RELU if relu else 0) | (GEMM_TRANS_A if trans_a else 0) | (GEMM_TRANS_B if trans_b else 0) | \
+        (GEMM_ATOMIC if atomic else 0) | (GEMM_ACCUM if accum else 0) | (GEMM_FORCE_GENERIC if force_generic else 0)
+    gemm_raw(a, b, out, M, N, K, a.stride(0), b.stride(0), out.stride(0), bias=bias, residual=residual, gate=gate,
+             ldr=residual.stride(0) if residual is not None else 0, ldg=gate.stride(0) if gate is not None else 0,
+             alpha=alpha, flags=flags, k_split=k_split)
+    return out
+
+
+def layernorm_fwd(x, gamma, beta, eps, pe=None, offsets=None, S=1):
+    _req_cuda(x)
+    rows, d = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty(rows, device=x.device, dtype=torch.float32)
+    rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
+    call("pero_layernorm_fwd", ptr(x), ptr(gamma), ptr(beta), ptr(pe), ptr(offsets), ptr(y), ptr(mean), ptr(rstd),
+         rows, d, S, float(eps), dt(x), stream())
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, dxsum=None):
+    rows, d = x.shape
+    dx = torch.empty_like(x)
+    call("pero_layernorm_bwd", ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(dx), ptr(dgamma), ptr(dbeta),
+         ptr(dxsum), rows, d, dt(x), stream())
+    return dx
+
+
+def softmax_fwd(scores, scale, out_dtype):
+    rows, cols = scores.numel() // scores.shape[-1], scores.shape[-1]
+    p = torch.empty(scores.shape, device=scores.device, dtype=out_dtype)
+    call("pero_softmax_fwd", ptr(scores), ptr(p), rows, cols, float(scale), dt(out_dtype), stream())
+    return p
+
+
+def softmax_bwd(p, dp, scale):
+    rows, cols = p.numel() // p.shape[-1], p.shape[-1]
+    ds = torch.empty_like(p)
+    call("pero_softmax_bwd", ptr(p), ptr(dp), ptr(ds), rows, cols, float(scale), dt(p), stream())
+    return ds
+
+
+def masked_ce(logits, labels, mask, unmasked_weight=None, want_grad=True):
+    """logits (rows,V); labels/mask int64 (rows).  Returns (loss f32 scalar tensor, dlogits or None)."""
+    _req_cuda(logits, labels, mask)
+    rows, V = logits.shape
+    loss = torch.empty(1, device=logits.device, dtype=torch.float32)
+    work = torch.empty(rows + 8, device=logits.device, dtype=torch.float32)
+    dlogits = torch.empty_like(logits) if want_grad else None
+    call("pero_masked_ce", ptr(logits), ptr(labels), ptr(mask), -1.0 if unmasked_weight is None else float(unmasked_weight),
+         ptr(loss), ptr(dlogits), ptr(work), rows, V, dt(logits), stream())
+    return loss, dlogits
+
+
+def colsum(x, out):
+    rows, cols = x.shape
+    call("pero_colsum", ptr(x), ptr(out), rows, cols, x.stride(0), dt(x), stream())
+    return out
+
+
+def cast_to_bf16(src, dst):
+    call("pero_cast_f32_bf16", ptr(src), ptr(dst), src.numel(), stream())
+    return dst
+
+
+def scale_(x, s):
+    call("pero_scale", ptr(x), x.numel(), float(s), dt(x), stream())
+    return x
+
+
+def patches_from_u8(images, mask, tile, P, dtype):
+    _req_cuda(images)
+    images = images.contiguous()
+    N, H, W, C = images.shape
+    out = torch.empty((N * (W // P), C * H * P), device=images.device, dtype=dtype)
+    call("pero_patches_from_u8", ptr(images), ptr(mask), ptr(tile), ptr(out), N, H, W, C, P, dt(dtype), stream())
+    return out
+
+
+def patches_from_f32(images, mask, tile, P, dtype):
+    _req_cuda(images)
+    images = images.contiguous()
+    N, C, H, W = images.shape
+    out = torch.empty((N * (W // P), C * H * P), device=images.device, dtype=dtype)
+    call("pero_patches_from_f32", ptr(images), ptr(mask), ptr(tile), ptr(out), N, H, W, C, P, dt(dtype), stream())
+    return out
+
+
+def apply_mask_(images, mask, tile, P):
+    _req_cuda(images)
+    N, C, H, W = images.shape
+    call("pero_apply_mask_f32", ptr(images), ptr(mask), ptr(tile), N, H, W, C, P, stream())
+    return images
+
+
+def adam_step(p, g, m, v, p_bf16, lr, beta1, beta2, eps, step, grad_scale=1.0):
+    call("pero_adam_step", ptr(p), ptr(g), ptr(m), ptr(v), ptr(p_bf16), p.numel(), float(lr), float(beta1), float(beta2),
+         float(eps), int(step), float(grad_scale), stream())
+
+
+def vq_argmin(x, codebook, want_dist=False):
+    _req_cuda(x, codebook)
+    M, D = x.shape
+    K = codebook.shape[0]
+    idx = torch.empty(M, device=x.device, dtype=torch.int64)
+    best = torch.empty(M, device=x.device, dtype=torch.float32) if want_dist else None
+    work = torch.empty(M + K, device=x.device, dtype=torch.float32)
+    call("pero_vq_argmin", ptr(x), ptr(codebook), ptr(idx), ptr(best), ptr(work), M, K, D, stream())
+    return (idx, best) if want_dist else idx
+
+
+def vq_gather(x, codebook, idx):
+    q = torch.empty_like(x)
+    call("pero_vq_gather", ptr(x), ptr(codebook), ptr(idx), ptr(q), x.shape[0], x.shape[1], stream())
+    return q
+
+
+def gather_rows(src, index, n_rows_out=None):
+    n_idx = index.numel()
+    n_out = n_idx if n_rows_out is None else n_rows_out
+    d = src.shape[-1]
+    dst = torch.empty((n_out, d), device=src.device, dtype=src.dtype)
+    call("pero_gather_rows", ptr(src), ptr(index), ptr(dst), n_idx, n_out, d, dt(src), stream())
+    return dst
+
+
+def scatter_add_rows(src, index, dst):
+    if index.numel():
+        call("pero_scatter_add_rows", ptr(src), ptr(index), ptr(dst), index.numel(), dst.shape[-1], dt(src), stream())
+    return dst

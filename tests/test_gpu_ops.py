@@ -1,0 +1,302 @@
+"""GPU parity of every C-ABI kernel against the CPU oracle (oracle/pero_oracle.py) on seeded inputs.
+Integer / index outputs are compared bit-exact; f32-mode kernels to 1e-5 relative (different f32
+summation order than the CPU), bf16-mode kernels against an f32 evaluation of the same bf16-rounded
+inputs with a tolerance set by the bf16 output rounding (2^-8 relative)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import pero_oracle as O  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from pero_pretraining_amd import ops as _ops
+    return _ops
+
+
+def dev(x, dtype=None):
+    t = torch.as_tensor(x).cuda()
+    return t if dtype is None else t.to(dtype)
+
+
+def rel_err(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+# ------------------------------------------------------------------------------------------------ gemm
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("M,N,K", [(70, 45, 33), (128, 64, 16), (1, 1, 1), (200, 130, 300)])
+def test_gemm_generic_f32(ops, ta, tb, M, N, K):
+    g = torch.Generator().manual_seed(M * 7 + N + K)
+    a = torch.randn((K, M) if ta else (M, K), generator=g)
+    b = torch.randn((K, N) if tb else (N, K), generator=g)
+    bias = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g)
+    gate = torch.randn(M, N, generator=g)
+    A = a.t() if ta else a
+    Bm = b.t() if tb else b
+    ref = torch.relu(0.5 * (A.double() @ Bm.double().t()) + bias.double() + res.double()) * (gate > 0)
+    out = ops.gemm(dev(a), dev(b), bias=dev(bias), residual=dev(res), gate=dev(gate), trans_a=ta, trans_b=tb,
+                   relu=True, alpha=0.5)
+    assert rel_err(out, ref) < 1e-5
+
+
+def test_gemm_generic_exact_integers_and_accumulate(ops):
+    g = torch.Generator().manual_seed(0)
+    a = torch.randint(-4, 5, (96, 40), generator=g).float()
+    b = torch.randint(-4, 5, (72, 40), generator=g).float()
+    ref = a @ b.t()
+    c = torch.ones(96, 72).cuda()
+    ops.gemm(dev(a), dev(b), out=c, accum=True)
+    assert torch.equal(c.cpu(), ref + 1)
+    ops.gemm(dev(a), dev(b), out=c, atomic=True)
+    assert torch.equal(c.cpu(), 2 * ref + 1)
+
+
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
+def test_gemm_bf16_fast_layouts_exact_integers(ops, ta, tb, out_dtype):
+    """Small integers: every product and partial sum is exact in bf16 x bf16 -> f32, so the fast MFMA
+    kernel (all four operand layouts, swizzled LDS images, transposed reads) must be bit-exact."""
+    M, N, K = 256, 384, 192
+    g = torch.Generator().manual_seed(3)
+    a = torch.randint(-3, 4, (K, M) if ta else (M, K), generator=g).float()
+    b = torch.randint(-3, 4, (K, N) if tb else (N, K), generator=g).float()
+    A = a.t() if ta else a
+    Bm = b.t() if tb else b
+    ref = A @ Bm.t()
+    out = ops.gemm(dev(a, torch.bfloat16), dev(b, torch.bfloat16), trans_a=ta, trans_b=tb, out_dtype=out_dtype)
+    assert out.dtype == out_dtype
+    # f32 accumulators are exact; a bf16 output rounds integers above 256 -> compare through that rounding
+    assert torch.equal(out.float().cpu(), ref.to(out_dtype).float())
+
+
+def test_gemm_bf16_fast_epilogues_and_splitk(ops):
+    M, N, K = 384, 256, 512
+    g = torch.Generator().manual_seed(5)
+    a = torch.randn(M, K, generator=g).bfloat16()
+    b = torch.randn(N, K, generator=g).bfloat16()
+    bias = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g).bfloat16()
+    gate = torch.randn(M, N, generator=g).bfloat16()
+    acc = a.double() @ b.double().t()
+    ref = torch.relu(0.25 * acc + bias.double() + res.double()) * (gate.double() > 0)
+    out = ops.gemm(dev(a), dev(b), bias=dev(bias), residual=dev(res), gate=dev(gate), relu=True, alpha=0.25)
+    assert rel_err(out, ref) < 2 ** -8
+    # fast kernel == generic exact-f32 kernel on the same bf16 inputs, up to f32 summation order + output rounding
+    out_g = ops.gemm(dev(a), dev(b), bias=dev(bias), residual=dev(res), gate=dev(gate), relu=True, alpha=0.25,
+                     force_generic=True)
+    assert rel_err(out, out_g.float()) < 2 ** -7
+    # split-K with f32 atomics (weight-gradient form: both operands K-major)
+    at, bt = a.t().contiguous(), b.t().contiguous()  # stored [K][M], [K][N]
+    c = torch.zeros(M, N, device="cuda")
+    ops.gemm(dev(at), dev(bt), out=c, trans_a=True, trans_b=True, atomic=True, k_split=4)
+    assert rel_err(c, acc) < 1e-5
+    ops.gemm(dev(at), dev(bt), out=c, trans_a=True, trans_b=True, atomic=True, k_split=3)
+    assert rel_err(c, 2 * acc) < 1e-5
+
+
+def test_gemm_batched_strided_attention_shapes(ops):
+    """Q K^T and P V as batched GEMMs straight out of the packed qkv tensor (two-level batch strides)."""
+    n, s, h, hd = 2, 256, 2, 128
+    d = h * hd
+    g = torch.Generator().manual_seed(9)
+    qkv = (torch.randn(n * s, 3 * d, generator=g) * 0.5).bfloat16()
+    qd = dev(qkv)
+    scores = torch.empty(n * h, s, s, device="cuda", dtype=torch.float32)
+    ops.gemm_raw(qd, qd[:, d:], scores, s, s, hd, 3 * d, 3 * d, s, batch=n * h, batch_inner=h,
+                 sA=(s * 3 * d, hd), sB=(s * 3 * d, hd), sC=(h * s * s, s * s))
+    q, k, v = qkv.double().reshape(n, s, 3, h, hd).permute(2, 0, 3, 1, 4)
+    ref = (q @ k.transpose(-1, -2)).reshape(n * h, s, s)
+    assert rel_err(scores, ref) < 1e-5
+    p = torch.softmax(ref / math.sqrt(hd), -1).bfloat16()
+    out = torch.empty(n * s, d, device="cuda", dtype=torch.bfloat16)
+    from pero_pretraining_amd._lib import GEMM_TRANS_B
+    ops.gemm_raw(dev(p), qd[:, 2 * d:], out, s, hd, s, s, 3 * d, d, batch=n * h, batch_inner=h,
+                 sA=(h * s * s, s * s), sB=(s * 3 * d, hd), sC=(s * d, hd), flags=GEMM_TRANS_B)
+    ref_o = (p.double().reshape(n, h, s, s) @ v).permute(0, 2, 1, 3).reshape(n * s, d)
+    assert rel_err(out, ref_o) < 2 ** -8
+
+
+# ------------------------------------------------------------------------------------------ row kernels
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,d", [(37, 64), (64, 256), (130, 512)])
+def test_layernorm_fwd_bwd(ops, dtype, rows, d):
+    g = torch.Generator().manual_seed(rows + d)
+    S = 1 if rows % 2 else rows // 2
+    x = (torch.randn(rows, d, generator=g) * 2 + 0.3).to(dtype)
+    gamma = torch.randn(d, generator=g)
+    beta = torch.randn(d, generator=g)
+    pe = O.positional_table(d, 512)
+    offsets = torch.randint(0, 512 - S, (rows // S,), generator=g)
+    xr = x.float().requires_grad_(True)
+    gr = gamma.clone().requires_grad_(True)
+    br = beta.clone().requires_grad_(True)
+    y_ref = O.add_positional(O.layer_norm(xr, gr, br), rows // S, S, pe, offsets)
+    dy = torch.randn(rows, d, generator=g).to(dtype)
+    y_ref.backward(dy.float())
+    y, mean, rstd = ops.layernorm_fwd(dev(x), dev(gamma), dev(beta), 1e-5, pe=dev(pe), offsets=dev(offsets), S=S)
+    tol = 1e-5 if dtype == torch.float32 else 2 ** -7
+    assert rel_err(y, y_ref.detach()) < tol
+    dg = torch.zeros(d, device="cuda")
+    db = torch.zeros(d, device="cuda")
+    dxs = torch.zeros(d, device="cuda")
+    dx = ops.layernorm_bwd(dev(dy), dev(x), mean, rstd, dev(gamma), dg, db, dxs)
+    assert rel_err(dx, xr.grad) < (2e-5 if dtype == torch.float32 else 2 ** -6)
+    assert rel_err(dg, gr.grad) < 1e-4
+    assert rel_err(db, br.grad) < 1e-4
+    assert rel_err(dxs, xr.grad.sum(0)) < 1e-4  # column sums are taken in f32 before dx is rounded
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_softmax_fwd_bwd(ops, dtype):
+    g = torch.Generator().manual_seed(1)
+    s = torch.randn(50, 100, generator=g) * 4
+    sr = s.clone().requires_grad_(True)
+    p_ref = torch.softmax(sr * 0.3, -1)
+    dp = torch.randn(50, 100, generator=g)
+    p_ref.backward(dp)
+    p = ops.softmax_fwd(dev(s), 0.3, dtype)
+    assert rel_err(p, p_ref.detach()) < (1e-6 if dtype == torch.float32 else 2 ** -8)
+    ds = ops.softmax_bwd(p, dev(dp), 0.3)
+    assert rel_err(ds, sr.grad) < (1e-5 if dtype == torch.float32 else 2 ** -6)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("uw", [None, 0.25])
+def test_masked_ce(ops, dtype, uw):
+    g = torch.Generator().manual_seed(2)
+    rows, V = 60, 333
+    logits = (torch.randn(rows, V, generator=g) * 3).to(dtype)
+    labels = torch.randint(0, V, (rows,), generator=g)
+    labels[50:] = -1
+    mask = (torch.rand(rows, generator=g) < 0.3).long() * (labels >= 0)
+    lr = logits.float().requires_grad_(True)
+    loss_ref = O.masked_cross_entropy(lr[None], labels[None], mask[None], uw)
+    loss_ref.backward()
+    loss, dl = ops.masked_ce(dev(logits), dev(labels), dev(mask), uw)
+    assert abs(float(loss) - float(loss_ref)) < 2e-6 * abs(float(loss_ref))
+    assert rel_err(dl, lr.grad) < (1e-5 if dtype == torch.float32 else 2 ** -7)
+
+
+def test_masked_ce_empty_mask_is_nan(ops):
+    logits = torch.randn(8, 16).cuda()
+    labels = torch.zeros(8, dtype=torch.long).cuda()
+    mask = torch.zeros(8, dtype=torch.long).cuda()
+    loss, _ = ops.masked_ce(logits, labels, mask)
+    assert math.isnan(float(loss))  # reference: cross_entropy over an empty selection is NaN
+
+
+def test_colsum_cast_scale(ops):
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(300, 1000, generator=g)
+    out = torch.ones(1000, device="cuda")
+    ops.colsum(dev(x), out)
+    assert rel_err(out, x.double().sum(0) + 1) < 1e-5
+    xb = dev(x.bfloat16())
+    out.zero_()
+    ops.colsum(xb[:, :512], out[:512])
+    assert rel_err(out[:512], x.bfloat16().double()[:, :512].sum(0)) < 1e-5
+    flat = torch.randn(100003, generator=g)
+    padded = torch.zeros(100008)
+    padded[:100003] = flat
+    dst = torch.empty(100008, device="cuda", dtype=torch.bfloat16)
+    ops.cast_to_bf16(dev(padded), dst)
+    assert torch.equal(dst.cpu(), padded.bfloat16())
+    y = dev(flat.clone())
+    ops.scale_(y, 0.5)
+    assert torch.equal(y.cpu(), flat * 0.5)
+
+
+def test_adam_matches_oracle(ops):
+    g = torch.Generator().manual_seed(6)
+    n = 10007
+    p = torch.randn(n, generator=g)
+    pd, md, vd = dev(p.clone()), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    pb = torch.empty(n, device="cuda", dtype=torch.bfloat16)
+    po, mo, vo = p.clone(), torch.zeros(n), torch.zeros(n)
+    for step in range(1, 5):
+        gr = torch.randn(n, generator=g) * (0.1 if step % 2 else 10)
+        O.adam_update(po, gr, mo, vo, step, 1e-3 * step)
+        ops.adam_step(pd, dev(gr), md, vd, pb, 1e-3 * step, 0.9, 0.999, 1e-8, step)
+    assert rel_err(pd, po) < 1e-6
+    assert rel_err(md, mo) < 1e-6 and rel_err(vd, vo) < 2e-6
+    assert torch.equal(pb.cpu(), pd.cpu().bfloat16())
+
+
+# ------------------------------------------------------------------------------------------ front end
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N,W", [(3, 128), (2, 200), (1, 8)])
+def test_patches(ops, dtype, N, W):
+    rng = np.random.default_rng(N * 100 + W)
+    images = rng.integers(0, 256, (N, 40, W, 3), dtype=np.uint8)
+    mask = (rng.random((N, W // 8)) < 0.3).astype(np.int64)
+    tile = O.mask_tile()
+    x = O.prepare_images(torch.from_numpy(images))
+    ref = O.patches(O.apply_mask(x, mask, tile))
+    out = ops.patches_from_u8(dev(images), dev(mask), dev(tile), 8, dtype)
+    if dtype == torch.float32:
+        assert torch.equal(out.cpu(), ref)  # u8/255 in f32: bit exact
+    else:
+        assert torch.equal(out.cpu(), ref.bfloat16())
+    out2 = ops.patches_from_f32(dev(x), dev(mask), dev(tile), 8, dtype)
+    assert torch.equal(out2.cpu(), ref.to(dtype))
+    out3 = ops.patches_from_u8(dev(images), None, None, 8, torch.float32)
+    assert torch.equal(out3.cpu(), O.patches(x))
+    xm = dev(x.contiguous())
+    ops.apply_mask_(xm, dev(mask), dev(tile), 8)
+    assert torch.equal(xm.cpu(), O.apply_mask(x, mask, tile))
+
+
+# ------------------------------------------------------------------------------------------ quantizer
+def test_vq_argmin_small_and_ragged(ops, golden):
+    g = golden("g6_quantizers.npz")
+    flat = np.ascontiguousarray(g["small.features"].transpose(0, 2, 3, 1)).reshape(-1, 32)
+    idx = ops.vq_argmin(dev(flat), dev(g["small.codebook"]))
+    assert np.array_equal(idx.cpu().numpy(), g["small.indices"])  # reference-generated indices, bit exact
+    q = ops.vq_gather(dev(flat), dev(g["small.codebook"]), idx)
+    qo, _ = O.vq_quantize(g["small.features"], g["small.codebook"])
+    assert np.array_equal(q.cpu().numpy().reshape(2, 1, 100, 32).transpose(0, 3, 1, 2), qo)
+    rng = np.random.default_rng(0)  # ragged sizes, duplicate codes (ties -> first index)
+    x = rng.standard_normal((77, 19)).astype(np.float32)
+    e = rng.standard_normal((130, 19)).astype(np.float32)
+    e[100] = e[3]
+    x[5] = e[3]
+    idx, best = ops.vq_argmin(dev(x), dev(e), want_dist=True)
+    ref, dist = O.vq_nearest(x, e)
+    assert np.array_equal(idx.cpu().numpy(), ref)
+    assert int(idx[5]) == 3
+
+
+def test_vq_argmin_codebook_8192(ops, golden):
+    g = golden("g6_quantizers.npz")
+    torch.manual_seed(5)
+    w = torch.nn.Embedding(8192, 512).weight.data
+    w.normal_()
+    flat = np.ascontiguousarray(g["cb8192.features"].transpose(0, 2, 3, 1)).reshape(-1, 512)
+    idx, best = ops.vq_argmin(dev(flat), dev(w), want_dist=True)
+    near_tie = (g["cb8192.second"] - g["cb8192.best"]) < 1e-4 * np.abs(g["cb8192.best"])
+    got = idx.cpu().numpy()
+    assert np.array_equal(got[~near_tie], g["cb8192.indices"][~near_tie])
+    assert (got != g["cb8192.indices"]).sum() <= near_tie.sum()
+    assert np.abs(best.cpu().numpy() - g["cb8192.best"]).max() < 1e-3
+
+
+def test_gather_scatter(ops):
+    g = torch.Generator().manual_seed(8)
+    for dtype in (torch.float32, torch.bfloat16):
+        src = torch.randn(50, 96, generator=g).to(dtype)
+        index = torch.randperm(50, generator=g)[:20]
+        out = ops.gather_rows(dev(src), dev(index), 24)
+        assert torch.equal(out[:20].cpu(), src[index]) and float(out[20:].float().abs().sum()) == 0
+        dst = dev(src.clone())
+        ops.scatter_add_rows(out, dev(index), dst)
+        ref = src.clone().float()
+        ref[index] += src[index].float()
+        assert torch.equal(dst.cpu(), ref.to(dtype))
