@@ -94,10 +94,14 @@ int pero_softmax_bwd(const void* p, const float* dp, void* ds, int64_t rows, int
 /* ---- masked cross entropy (masked_pretraining/model.py:72-95) -------------------------------------------
  * logits (rows, V); labels, mask int64 (rows).  loss_out[0] = mean CE over mask==1 rows
  * (+ unmasked_weight * mean CE over mask==0 & label>=0 rows when unmasked_weight >= 0; pass a negative
- * value for "None").  dlogits (same dtype/shape as logits, may be null) = d loss / d logits.
- * work: f32 workspace of at least rows + 8 elements.  Empty selections give NaN like the reference. */
-int pero_masked_ce(const void* logits, const int64_t* labels, const int64_t* mask, float unmasked_weight,
-                   float* loss_out, void* dlogits, float* work, int64_t rows, int64_t V, int dtype, void* stream);
+ * value for "None").  work: f32 workspace of 2*rows + 8 elements, kept by the caller for the backward
+ * call (row losses, the two row counts, row logsumexps).  Empty selections give NaN like the reference.
+ * bwd: dlogits (dtype, rows x V) = dloss[0] * d loss / d logits (dloss: device f32 scalar, null = 1). */
+int pero_masked_ce_fwd(const void* logits, const int64_t* labels, const int64_t* mask, float unmasked_weight,
+                       float* loss_out, float* work, int64_t rows, int64_t V, int dtype, void* stream);
+int pero_masked_ce_bwd(const void* logits, const int64_t* labels, const int64_t* mask, float unmasked_weight,
+                       const float* dloss, const float* work, void* dlogits, int64_t rows, int64_t V, int dtype,
+                       void* stream);
 
 /* ---- reductions / elementwise ---------------------------------------------------------------------- */
 /* out[n] += sum_m x[m][n]  (bias gradients); out f32 */
@@ -111,8 +115,8 @@ int pero_scale(void* x, int64_t n, float scale, int dtype, void* stream);
 /* ---- Adam (torch.optim.Adam defaults: masked_pretraining/train.py:146) ----------------------------------
  * one launch over a flat f32 parameter / gradient / moment buffer; `step` is 1-based; optionally also
  * writes the bf16 copy of the updated parameters (p_bf16 may be null). */
-int pero_adam_step(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr,
-                   float beta1, float beta2, float eps, int64_t step, float grad_scale, void* stream);
+int pero_adam_step(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, double lr,
+                   double beta1, double beta2, double eps, int64_t step, double grad_scale, void* stream);
 
 /* ---- quantizers (models/autoencoders.py:212-217 ; scripts/produce_kmeans_labels.py:72-76) ---------------
  * indices[m] = argmin_k ( sum(x_m^2) + sum(e_k^2) - 2 x_m . e_k )  in exact f32, first minimum wins.

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libpero_hip.so")
 PERO_F32, PERO_BF16 = 0, 1
 GEMM_RELU, GEMM_ATOMIC, GEMM_ACCUM, GEMM_TRANS_A, GEMM_TRANS_B, GEMM_FORCE_GENERIC = 1, 2, 4, 8, 16, 32
 
-_vp, _i64, _i32, _f32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float
+_vp, _i64, _i32, _f32, _f64 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_double
 
 # name -> argtypes (all functions return int unless noted)
 SIGNATURES = {
@@ -25,12 +25,13 @@ SIGNATURES = {
     "pero_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp],
     "pero_softmax_fwd": [_vp, _vp, _i64, _i64, _f32, _i32, _vp],
     "pero_softmax_bwd": [_vp, _vp, _vp, _i64, _i64, _f32, _i32, _vp],
-    "pero_masked_ce": [_vp, _vp, _vp, _f32, _vp, _vp, _vp, _i64, _i64, _i32, _vp],
+    "pero_masked_ce_fwd": [_vp, _vp, _vp, _f32, _vp, _vp, _i64, _i64, _i32, _vp],
+    "pero_masked_ce_bwd": [_vp, _vp, _vp, _f32, _vp, _vp, _vp, _i64, _i64, _i32, _vp],
     "pero_colsum": [_vp, _vp, _i64, _i64, _i64, _i32, _vp],
     "pero_cast_f32_bf16": [_vp, _vp, _i64, _vp],
     "pero_cast_bf16_f32": [_vp, _vp, _i64, _vp],
     "pero_scale": [_vp, _i64, _f32, _i32, _vp],
-    "pero_adam_step": [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _i64, _f32, _vp],
+    "pero_adam_step": [_vp, _vp, _vp, _vp, _vp, _i64, _f64, _f64, _f64, _f64, _i64, _f64, _vp],
     "pero_vq_argmin": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp],
     "pero_vq_gather": [_vp, _vp, _vp, _vp, _i64, _i64, _vp],
     "pero_gather_rows": [_vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp],

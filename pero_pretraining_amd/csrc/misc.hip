@@ -189,14 +189,14 @@ __global__ __launch_bounds__(256) void adam_k(float* p, const float* g, float* m
     }
   }
 }
-extern "C" int pero_adam_step(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr, float beta1,
-                              float beta2, float eps, int64_t step, float grad_scale, void* stream) {
+extern "C" int pero_adam_step(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, double lr, double beta1,
+                              double beta2, double eps, int64_t step, double grad_scale, void* stream) {
   PERO_REQUIRE(p && g && m && v && n > 0 && step >= 1, "pero_adam_step: bad arguments");
   PERO_REQUIRE(aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v) && (!p_bf16 || (((uintptr_t)p_bf16) & 7) == 0), "pero_adam_step: alignment");
-  const double bc1 = 1.0 - pow((double)beta1, (double)step);
-  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  const double bc1 = 1.0 - pow(beta1, (double)step);
+  const double bc2 = 1.0 - pow(beta2, (double)step);
   hipLaunchKernelGGL(adam_k, dim3(grid_for(n, 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16raw*)p_bf16, (long long)n,
-                     (float)((double)lr / bc1), beta1, beta2, (float)(1.0 - (double)beta1), (float)(1.0 - (double)beta2), eps, (float)(1.0 / sqrt(bc2)), grad_scale);
+                     (float)(lr / bc1), (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, (float)(1.0 / sqrt(bc2)), (float)grad_scale);
   PERO_CHECK_LAUNCH("pero_adam_step");
   return PERO_OK;
 }

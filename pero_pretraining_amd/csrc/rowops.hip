@@ -251,7 +251,8 @@ extern "C" int pero_softmax_bwd(const void* p, const float* dp, void* ds, int64_
 }
 
 // ---------------------------------------------------------------------------------------------
-// masked cross entropy.  work[0..rows) = per-row loss, work[rows+0] = n_masked, work[rows+1] = n_unmasked
+// masked cross entropy.  work[0..rows) = per-row loss, work[rows+0] = n_masked, work[rows+1] = n_unmasked,
+// work[rows+8 .. 2*rows+8) = per-row logsumexp (kept for the backward kernel)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ce_count_k(const int64_t* labels, const int64_t* mask, float* work, long long rows) {
   __shared__ int sm[2][4];
@@ -269,21 +270,18 @@ __global__ __launch_bounds__(256) void ce_count_k(const int64_t* labels, const i
     work[rows + 1] = (float)(sm[1][0] + sm[1][1] + sm[1][2] + sm[1][3]);
   }
 }
+// forward: per-row loss -> work[row], per-row logsumexp -> work[rows + 8 + row]
 template <typename T>
 __global__ __launch_bounds__(256) void ce_rows_k(const T* logits, const int64_t* labels, const int64_t* mask, float uw,
-                                                 T* dlogits, float* work, long long rows, int V) {
+                                                 float* work, long long rows, int V) {
   __shared__ float red[4];
   const long long row = blockIdx.x;
   const int tid = threadIdx.x;
   const long long lab = labels[row];
   const long long mk = mask[row];
-  float w = 0.f;
-  if (mk == 1) w = 1.0f / work[rows];
-  else if (mk == 0 && lab >= 0 && uw >= 0.f) w = uw / work[rows + 1];
   const bool active = (mk == 1) || (mk == 0 && lab >= 0 && uw >= 0.f);
   if (!active) {
-    if (tid == 0) work[row] = 0.f;
-    if (dlogits) for (int c = tid; c < V; c += 256) Elem<T>::st(dlogits + row * V + c, 0.f);
+    if (tid == 0) { work[row] = 0.f; work[rows + 8 + row] = 0.f; }
     return;
   }
   const T* lr = logits + row * V;
@@ -301,14 +299,31 @@ __global__ __launch_bounds__(256) void ce_rows_k(const T* logits, const int64_t*
   __syncthreads();
   sum = (red[0] + red[1]) + (red[2] + red[3]);
   const float lse = logf(sum) + mx;
-  if (tid == 0) work[row] = lse - Elem<T>::ld(lr + lab);
-  if (dlogits) {
-    const float inv = 1.0f / sum;
-    for (int c = tid; c < V; c += 256) {
-      float g = expf(Elem<T>::ld(lr + c) - mx) * inv;
-      if (c == lab) g -= 1.0f;
-      Elem<T>::st(dlogits + row * V + c, g * w);
-    }
+  if (tid == 0) { work[row] = lse - Elem<T>::ld(lr + lab); work[rows + 8 + row] = lse; }
+}
+// backward: dlogits[row] = (softmax(logits[row]) - onehot(label)) * weight(row) * dloss
+template <typename T>
+__global__ __launch_bounds__(256) void ce_bwd_k(const T* logits, const int64_t* labels, const int64_t* mask, float uw,
+                                                const float* dloss, const float* work, T* dlogits, long long rows, int V) {
+  const long long row = blockIdx.x;
+  const int tid = threadIdx.x;
+  const long long lab = labels[row];
+  const long long mk = mask[row];
+  float w = 0.f;
+  if (mk == 1) w = 1.0f / work[rows];
+  else if (mk == 0 && lab >= 0 && uw >= 0.f) w = uw / work[rows + 1];
+  const bool active = (mk == 1) || (mk == 0 && lab >= 0 && uw >= 0.f);
+  if (!active) {
+    for (int c = tid; c < V; c += 256) Elem<T>::st(dlogits + row * V + c, 0.f);
+    return;
+  }
+  if (dloss) w *= dloss[0];
+  const float lse = work[rows + 8 + row];
+  const T* lr = logits + row * V;
+  for (int c = tid; c < V; c += 256) {
+    float g = expf(Elem<T>::ld(lr + c) - lse);
+    if (c == lab) g -= 1.0f;
+    Elem<T>::st(dlogits + row * V + c, g * w);
   }
 }
 __global__ __launch_bounds__(256) void ce_final_k(const int64_t* labels, const int64_t* mask, float uw, const float* work,
@@ -328,17 +343,29 @@ __global__ __launch_bounds__(256) void ce_final_k(const int64_t* labels, const i
     loss[0] = l;
   }
 }
-extern "C" int pero_masked_ce(const void* logits, const int64_t* labels, const int64_t* mask, float unmasked_weight,
-                              float* loss_out, void* dlogits, float* work, int64_t rows, int64_t V, int dtype, void* stream) {
-  PERO_REQUIRE(logits && labels && mask && loss_out && work, "pero_masked_ce: null pointer");
-  PERO_REQUIRE(rows > 0 && V > 0 && rows < 16777216, "pero_masked_ce: bad sizes");
+extern "C" int pero_masked_ce_fwd(const void* logits, const int64_t* labels, const int64_t* mask, float unmasked_weight,
+                                  float* loss_out, float* work, int64_t rows, int64_t V, int dtype, void* stream) {
+  PERO_REQUIRE(logits && labels && mask && loss_out && work, "pero_masked_ce_fwd: null pointer");
+  PERO_REQUIRE(rows > 0 && V > 0 && rows < 16777216, "pero_masked_ce_fwd: bad sizes");
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(ce_count_k, dim3(1), dim3(256), 0, st, labels, mask, work, (long long)rows);
-  if (dtype == PERO_F32) hipLaunchKernelGGL((ce_rows_k<float>), dim3((unsigned)rows), dim3(256), 0, st, (const float*)logits, labels, mask, unmasked_weight, (float*)dlogits, work, (long long)rows, (int)V);
-  else if (dtype == PERO_BF16) hipLaunchKernelGGL((ce_rows_k<bf16raw>), dim3((unsigned)rows), dim3(256), 0, st, (const bf16raw*)logits, labels, mask, unmasked_weight, (bf16raw*)dlogits, work, (long long)rows, (int)V);
-  else PERO_REQUIRE(false, "pero_masked_ce: bad dtype");
+  if (dtype == PERO_F32) hipLaunchKernelGGL((ce_rows_k<float>), dim3((unsigned)rows), dim3(256), 0, st, (const float*)logits, labels, mask, unmasked_weight, work, (long long)rows, (int)V);
+  else if (dtype == PERO_BF16) hipLaunchKernelGGL((ce_rows_k<bf16raw>), dim3((unsigned)rows), dim3(256), 0, st, (const bf16raw*)logits, labels, mask, unmasked_weight, work, (long long)rows, (int)V);
+  else PERO_REQUIRE(false, "pero_masked_ce_fwd: bad dtype");
   hipLaunchKernelGGL(ce_final_k, dim3(1), dim3(256), 0, st, labels, mask, unmasked_weight, work, loss_out, (long long)rows);
-  PERO_CHECK_LAUNCH("pero_masked_ce");
+  PERO_CHECK_LAUNCH("pero_masked_ce_fwd");
+  return PERO_OK;
+}
+extern "C" int pero_masked_ce_bwd(const void* logits, const int64_t* labels, const int64_t* mask, float unmasked_weight,
+                                  const float* dloss, const float* work, void* dlogits, int64_t rows, int64_t V, int dtype,
+                                  void* stream) {
+  PERO_REQUIRE(logits && labels && mask && work && dlogits, "pero_masked_ce_bwd: null pointer");
+  PERO_REQUIRE(rows > 0 && V > 0, "pero_masked_ce_bwd: bad sizes");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == PERO_F32) hipLaunchKernelGGL((ce_bwd_k<float>), dim3((unsigned)rows), dim3(256), 0, st, (const float*)logits, labels, mask, unmasked_weight, dloss, work, (float*)dlogits, (long long)rows, (int)V);
+  else if (dtype == PERO_BF16) hipLaunchKernelGGL((ce_bwd_k<bf16raw>), dim3((unsigned)rows), dim3(256), 0, st, (const bf16raw*)logits, labels, mask, unmasked_weight, dloss, work, (bf16raw*)dlogits, (long long)rows, (int)V);
+  else PERO_REQUIRE(false, "pero_masked_ce_bwd: bad dtype");
+  PERO_CHECK_LAUNCH("pero_masked_ce_bwd");
   return PERO_OK;
 }
 

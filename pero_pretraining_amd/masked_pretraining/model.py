@@ -1,0 +1,134 @@
+"""Masked pre-training model with the API of the reference's masked_pretraining/model.py
+(init_backbone, init_head, MaskedTransformerEncoder, MaskedCrossEntropyLoss, LinearHead), computing
+through the HIP kernels."""
+import torch
+
+from .. import functional as F
+from .. import lowp, ops
+from ..models.transformers import VisionTransformerEncoder
+from ..precision import compute_dtype
+
+
+def init_backbone(backbone_definition):
+    """masked_pretraining/model.py:7-17 (the whole dict is splatted into the constructor)."""
+    backbone_type = backbone_definition.get("type", "vit")
+    if backbone_type == "vit":
+        return VisionTransformerEncoder(**backbone_definition)
+    if backbone_type == "vggt":
+        raise NotImplementedError("vggt (VGG convolutional front end) is outside the HIP hot path (SURVEY.md section 2)")
+    raise ValueError(f"Unknown backbone type: {backbone_type}")
+
+
+def init_head(head_definition):
+    """masked_pretraining/model.py:20-30 (pops "type" from the caller's dict, like the reference)."""
+    head_type = head_definition.get("type", "linear")
+    if "type" in head_definition:
+        del head_definition["type"]
+    if head_type == "linear":
+        return LinearHead(**head_definition)
+    raise ValueError(f"Unknown head type: {head_type}")
+
+
+class _LinearFn(torch.autograd.Function):
+    """y = x W^T + b on token rows.  relu_out fuses a ReLU into the GEMM epilogue; gate_in declares that x
+    itself is the output of such a fused ReLU, so dx is gated by (x > 0) in the backward GEMM epilogue
+    (that IS the ReLU backward) - used by the MLP head chain."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, dtype, relu_out, gate_in):
+        x2 = x.detach().reshape(-1, x.shape[-1])
+        if x2.dtype != dtype or not x2.is_contiguous():
+            x2 = x2.to(dtype).contiguous()
+        y = F.linear_fwd(x2, weight, bias, dtype, relu=relu_out)
+        ctx.dtype, ctx.gate_in, ctx.x_shape = dtype, gate_in, x.shape
+        ctx.weight, ctx.bias = weight, bias
+        ctx.save_for_backward(x2)
+        return y.view(*x.shape[:-1], weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x2,) = ctx.saved_tensors
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        if dy2.dtype != ctx.dtype or not dy2.is_contiguous():
+            dy2 = dy2.to(ctx.dtype).contiguous()
+        dx = F.linear_bwd(dy2, x2, ctx.weight, ctx.bias, ctx.dtype, need_dx=ctx.needs_input_grad[0],
+                          gate=x2 if ctx.gate_in else None)
+        return (dx.view(ctx.x_shape) if dx is not None else None), None, None, None, None, None
+
+
+def linear(x, weight, bias, relu_out=False, gate_in=False):
+    if not x.is_cuda:
+        raise RuntimeError("pero_pretraining_amd layers run on the GPU only (HIP kernels, no CPU fallback)")
+    return _LinearFn.apply(x, weight, bias, compute_dtype(), relu_out, gate_in)
+
+
+class LinearHead(torch.nn.Module):
+    def __init__(self, in_features=512, out_features=4096):
+        super().__init__()
+        self.linear = torch.nn.Linear(in_features, out_features)  # parameter container (same init / keys)
+
+    def forward(self, x):
+        return linear(x, self.linear.weight, self.linear.bias)
+
+
+class _MaskedCEFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, output, labels, mask, unmasked_weight):
+        lg = output.detach().reshape(-1, output.shape[-1])
+        if not lg.is_contiguous():
+            lg = lg.contiguous()
+        lab = labels.reshape(-1).to(device=lg.device, dtype=torch.int64).contiguous()
+        msk = mask.reshape(-1).to(device=lg.device, dtype=torch.int64).contiguous()
+        loss, work = ops.masked_ce_fwd(lg, lab, msk, unmasked_weight)
+        ctx.save_for_backward(lg, lab, msk, work)
+        ctx.shape, ctx.uw = output.shape, unmasked_weight
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, dloss):
+        lg, lab, msk, work = ctx.saved_tensors
+        dl = dloss.detach().reshape(1).to(torch.float32)  # stays on the device: no host sync
+        return ops.masked_ce_bwd(lg, lab, msk, work, ctx.uw, dloss=dl).view(ctx.shape), None, None, None
+
+
+class MaskedCrossEntropyLoss(torch.nn.Module):
+    """masked_pretraining/model.py:72-95."""
+
+    def __init__(self, unmasked_weight=None):
+        super().__init__()
+        self.unmasked_weight = unmasked_weight
+
+    def forward(self, output, labels, mask):
+        if not isinstance(mask, torch.Tensor):
+            mask = torch.as_tensor(mask)
+        return _MaskedCEFn.apply(output, labels, mask, self.unmasked_weight)
+
+
+class MaskedTransformerEncoder(torch.nn.Module):
+    """masked_pretraining/model.py:33-69."""
+
+    def __init__(self, backbone, head, loss=None):
+        super().__init__()
+        self.backbone = backbone
+        self.head = head
+        self.loss = MaskedCrossEntropyLoss() if loss is None else loss
+
+    def forward(self, x, labels=None, mask=None):
+        output = self.encode(x, mask)
+        if mask is not None and not isinstance(mask, torch.Tensor):
+            mask = torch.from_numpy(mask).to(output.device)
+        loss = None
+        if mask is not None and labels is not None:
+            loss = self.loss(output, labels, mask)
+        return {"output": output, "loss": loss}
+
+    def encode(self, images, mask=None):
+        n = images.shape[0]
+        tokens = self.backbone.encode_tokens(images, mask)          # (N*S, d) row-major
+        return self.head(tokens.view(n, -1, tokens.shape[-1]))     # == head(rearrange(backbone(x), 'n c w -> n w c'))
+
+    def save(self, path):
+        torch.save(self.state_dict(), path)
+
+    def load(self, path):
+        self.load_state_dict(torch.load(path))

@@ -63,7 +63,7 @@ class PositionalEncoding(torch.nn.Module):
 class _BackboneFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mod, x, mask, offsets, dtype, *params):
-        save = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        save = any(ctx.needs_input_grad)
         tokens, saved = F.backbone_fwd(mod, x, mask, offsets, dtype, save)
         ctx.mod, ctx.saved, ctx.dtype = mod, saved, dtype
         return tokens

@@ -93,16 +93,23 @@ def softmax_bwd(p, dp, scale):
     return ds
 
 
-def masked_ce(logits, labels, mask, unmasked_weight=None, want_grad=True):
-    """logits (rows,V); labels/mask int64 (rows).  Returns (loss f32 scalar tensor, dlogits or None)."""
+def masked_ce_fwd(logits, labels, mask, unmasked_weight=None):
+    """logits (rows,V); labels/mask int64 (rows).  Returns (loss: f32 tensor of 1 element, work buffer)."""
     _req_cuda(logits, labels, mask)
     rows, V = logits.shape
     loss = torch.empty(1, device=logits.device, dtype=torch.float32)
-    work = torch.empty(rows + 8, device=logits.device, dtype=torch.float32)
-    dlogits = torch.empty_like(logits) if want_grad else None
-    call("pero_masked_ce", ptr(logits), ptr(labels), ptr(mask), -1.0 if unmasked_weight is None else float(unmasked_weight),
-         ptr(loss), ptr(dlogits), ptr(work), rows, V, dt(logits), stream())
-    return loss, dlogits
+    work = torch.empty(2 * rows + 8, device=logits.device, dtype=torch.float32)
+    call("pero_masked_ce_fwd", ptr(logits), ptr(labels), ptr(mask), -1.0 if unmasked_weight is None else float(unmasked_weight),
+         ptr(loss), ptr(work), rows, V, dt(logits), stream())
+    return loss, work
+
+
+def masked_ce_bwd(logits, labels, mask, work, unmasked_weight=None, dloss=None):
+    rows, V = logits.shape
+    dlogits = torch.empty_like(logits)
+    call("pero_masked_ce_bwd", ptr(logits), ptr(labels), ptr(mask), -1.0 if unmasked_weight is None else float(unmasked_weight),
+         ptr(dloss), ptr(work), ptr(dlogits), rows, V, dt(logits), stream())
+    return dlogits
 
 
 def colsum(x, out):

@@ -1,0 +1,168 @@
+"""GPU parity of the drop-in modules (pero_pretraining_amd.masked_pretraining / models) against golden
+vectors produced by the reference itself (tests/golden, oracle/make_golden.py) and against the CPU oracle.
+Bars: f32 mode - losses within 1e-4 relative (north_star), outputs 1e-4 absolute on O(1) logits,
+gradients 1e-3 relative to the tensor's max; bf16 mode - 3e-2 relative on the loss (bf16 operands)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import pero_oracle as O  # noqa: E402
+
+
+def sd_from(fix, prefix="sd."):
+    return {k[len(prefix):]: torch.from_numpy(fix[k]) for k in fix.files if k.startswith(prefix)}
+
+
+def build_tiny(sd=None):
+    from pero_pretraining_amd.masked_pretraining import model as M
+    bb = M.init_backbone({"type": "vit", "num_blocks": 2, "model_dim": 64, "num_heads": 4, "feedforward_dim": 128})
+    hd = M.init_head({"type": "linear", "in_features": 64, "out_features": 96})
+    model = M.MaskedTransformerEncoder(bb, hd)
+    if sd is not None:
+        model.load_state_dict(sd)
+    return model.cuda()
+
+
+def test_state_dict_keys_match_reference(golden):
+    g = golden("g4_masked_tiny.npz")
+    model = build_tiny()
+    assert list(model.state_dict().keys()) == list(sd_from(g).keys())
+
+
+@pytest.mark.parametrize("input_kind", ["u8_nhwc", "f32_nchw"])
+def test_masked_tiny_eval_forward_backward(golden, input_kind):
+    g = golden("g4_masked_tiny.npz")
+    model = build_tiny(sd_from(g)).eval()
+    labels = torch.from_numpy(g["labels"]).cuda()
+    if input_kind == "u8_nhwc":
+        x = torch.from_numpy(g["images"]).cuda()
+    else:
+        x = O.prepare_images(torch.from_numpy(g["images"])).contiguous().cuda()
+    res = model(x, labels, g["mask"].copy())
+    assert res["output"].shape == g["eval_output"].shape
+    assert np.abs(res["output"].detach().float().cpu().numpy() - g["eval_output"]).max() < 1e-4
+    assert abs(float(res["loss"]) - float(g["eval_loss"])) < 1e-4 * abs(float(g["eval_loss"]))
+    if input_kind == "f32_nchw":  # reference semantic: backbone.mask overwrites the caller's tensor
+        assert np.array_equal(x[:, :, :, :64].cpu().numpy(), g["masked_images_sample"])
+    model.zero_grad()
+    res["loss"].backward()
+    for k, p in model.named_parameters():
+        ref = g["grad." + k]
+        err = np.abs(p.grad.cpu().numpy() - ref).max()
+        assert err <= 1e-3 * max(np.abs(ref).max(), 1e-3), (k, err, np.abs(ref).max())
+    # (N, d, S) backbone output, as the reference returns it
+    xb = torch.from_numpy(g["images"]).cuda()
+    bo = model.backbone(xb, g["mask"].copy())
+    assert bo.shape == g["backbone_eval"].shape
+    assert np.abs(bo.detach().float().cpu().numpy() - g["backbone_eval"]).max() < 1e-4
+    out_nm = model(torch.from_numpy(g["images"]).cuda())["output"]
+    assert np.abs(out_nm.detach().float().cpu().numpy() - g["eval_output_nomask"]).max() < 1e-4
+
+
+def test_masked_tiny_train_mode_offsets_and_unmasked_weight(golden):
+    from pero_pretraining_amd.masked_pretraining.model import MaskedCrossEntropyLoss
+    g = golden("g4_masked_tiny.npz")
+    model = build_tiny(sd_from(g)).train()
+    x = torch.from_numpy(g["images"]).cuda()
+    labels = torch.from_numpy(g["labels"]).cuda()
+    model.backbone.set_offsets(g["train_offsets"])
+    res = model(x, labels, g["mask"].copy())
+    assert np.abs(res["output"].detach().float().cpu().numpy() - g["train_output"]).max() < 1e-4
+    assert abs(float(res["loss"]) - float(g["train_loss"])) < 1e-4 * float(g["train_loss"])
+    lw = MaskedCrossEntropyLoss(unmasked_weight=0.25)(res["output"], labels, torch.from_numpy(g["mask"]).cuda())
+    assert abs(float(lw) - float(g["train_loss_unmasked_w025"])) < 1e-4 * float(g["train_loss_unmasked_w025"])
+    # train-mode offsets drawn like the reference: same torch.randint call on the same device RNG stream
+    model.backbone.set_offsets(None)
+    torch.manual_seed(123)
+    expect = torch.randint(0, 4096 - 16, (3,), device="cuda")
+    torch.manual_seed(123)
+    got = model.backbone.position_model.draw_offsets(3, 16, torch.device("cuda", 0))
+    assert torch.equal(expect, got)
+
+
+def test_bf16_mode_close_to_f32(golden):
+    import pero_pretraining_amd as P
+    g = golden("g4_masked_tiny.npz")
+    model = build_tiny(sd_from(g)).eval()
+    x = torch.from_numpy(g["images"]).cuda()
+    labels = torch.from_numpy(g["labels"]).cuda()
+    with P.autocast(True):
+        res = model(x, labels, g["mask"].copy())
+    assert res["output"].dtype == torch.bfloat16
+    assert abs(float(res["loss"]) - float(g["eval_loss"])) < 3e-2 * float(g["eval_loss"])
+    model.zero_grad()
+    res["loss"].backward()
+    for k, p in model.named_parameters():
+        ref = g["grad." + k]
+        if np.abs(ref).max() < 1e-6:
+            continue
+        cos = float((p.grad.cpu().double().flatten() @ torch.from_numpy(ref).double().flatten()) /
+                    (p.grad.cpu().double().norm() * np.linalg.norm(ref.astype(np.float64)) + 1e-30))
+        assert cos > 0.98, (k, cos)
+    with torch.autocast(device_type="cuda", dtype=torch.bfloat16):  # the reference Trainer's own switch
+        res2 = model(x, labels, g["mask"].copy())
+    assert res2["output"].dtype == torch.bfloat16 and float(res2["loss"]) == float(res["loss"])
+
+
+def test_trajectory_three_steps_fused_adam(golden):
+    from pero_pretraining_amd.common.lr_scheduler import WarmupSchleduler
+    from pero_pretraining_amd.masked_pretraining.batch_operator import BatchOperator
+    from pero_pretraining_amd.masked_pretraining.trainer import Trainer
+    from pero_pretraining_amd.optim import FusedAdam
+    g = golden("g5_trajectory.npz")
+    model = build_tiny(sd_from(g, "sd0.")).train()
+    opt = FusedAdam(model.parameters(), lr=2e-3)
+    sched = WarmupSchleduler(opt, 2e-3, 2, 1)
+    trainer = Trainer(BatchOperator(torch.device("cuda", 0), 0.15), model, None, opt, sched, bfloat16=False)
+    np.random.seed(5)  # the mask sequence of the reference run (BatchOperator draws from the global numpy RNG)
+    for i in range(3):
+        sched.update_learning_rate(i + 1)
+        assert sched.current_lr == float(g["lr"][i])
+        model.backbone.set_offsets(g["offsets"][i])
+        batch = {"images": g["images"][i], "labels": g["labels"][i]}
+        st = np.random.get_state()
+        assert np.array_equal(trainer.batch_operator._create_mask(batch), g["mask"][i])
+        np.random.set_state(st)
+        loss = trainer.train_step(batch)
+        assert abs(float(loss) - float(g["loss"][i])) < 1e-4 * float(g["loss"][i]), (i, float(loss), g["loss"][i])
+    sd3 = sd_from(g, "sd3.")
+    for k, v in model.state_dict().items():
+        got, ref = v.cpu().numpy(), sd3[k].numpy()
+        if k.endswith("in_proj_bias"):  # key-bias slice: mathematically zero gradient, Adam amplifies rounding noise
+            d = got.shape[0] // 3
+            got, ref = np.delete(got, np.s_[d:2 * d]), np.delete(ref, np.s_[d:2 * d])
+        assert np.abs(got - ref).max() < 5e-4, k
+
+
+def test_config1_seed_recipe_matches_reference(golden):
+    """Config 1 (4 layers, d=256, B=8, 40x512): weights from torch.manual_seed(0) + the constructors (same RNG
+    draws as the reference), loss and sampled logits against the reference's CPU run."""
+    from pero_pretraining_amd.masked_pretraining import model as M
+    g = golden("g4c_config1.npz")
+    torch.manual_seed(0)
+    bb = M.init_backbone({"type": "vit", "num_blocks": 4, "model_dim": 256, "num_heads": 4, "feedforward_dim": 1024})
+    hd = M.init_head({"in_features": 256, "out_features": 4096})
+    model = M.MaskedTransformerEncoder(bb, hd)
+    sd = model.state_dict()
+    assert list(sd.keys()) == list(g["param_names"])
+    sums = np.array([float(v.double().sum()) for v in sd.values()])
+    assert np.allclose(sums, g["param_checksums"], rtol=0, atol=1e-9)
+    model = model.cuda().eval()
+    rng1 = np.random.default_rng(1234)
+    images = rng1.integers(0, 256, (8, 40, 512, 3), dtype=np.uint8)
+    labels = rng1.integers(0, 4096, (8, 64)).astype(np.int64)
+    mask = (rng1.random((8, 64)) < 0.15).astype(np.int64)
+    res = model(torch.from_numpy(images).cuda(), torch.from_numpy(labels).cuda(), mask)
+    assert abs(float(res["loss"]) - float(g["eval_loss"])) < 1e-4 * float(g["eval_loss"])
+    samples = res["output"].detach().float().cpu().numpy().reshape(-1)[g["logit_sample_index"]]
+    assert np.abs(samples - g["logit_samples"]).max() < 1e-4
+    model.zero_grad()
+    res["loss"].backward()
+    norms = np.array([float(p.grad.double().norm()) for _, p in model.named_parameters()])
+    assert np.allclose(norms, g["grad_norms"], rtol=2e-3, atol=1e-7)
+    model.train()
+    model.backbone.set_offsets(g["train_offsets"])
+    res = model(torch.from_numpy(images).cuda(), torch.from_numpy(labels).cuda(), mask)
+    assert abs(float(res["loss"]) - float(g["train_loss"])) < 1e-4 * float(g["train_loss"])

@@ -180,16 +180,19 @@ def test_masked_ce(ops, dtype, uw):
     lr = logits.float().requires_grad_(True)
     loss_ref = O.masked_cross_entropy(lr[None], labels[None], mask[None], uw)
     loss_ref.backward()
-    loss, dl = ops.masked_ce(dev(logits), dev(labels), dev(mask), uw)
+    loss, work = ops.masked_ce_fwd(dev(logits), dev(labels), dev(mask), uw)
     assert abs(float(loss) - float(loss_ref)) < 2e-6 * abs(float(loss_ref))
+    dl = ops.masked_ce_bwd(dev(logits), dev(labels), dev(mask), work, uw)
     assert rel_err(dl, lr.grad) < (1e-5 if dtype == torch.float32 else 2 ** -7)
+    dl2 = ops.masked_ce_bwd(dev(logits), dev(labels), dev(mask), work, uw, dloss=torch.full((1,), 0.5, device="cuda"))
+    assert rel_err(dl2, 0.5 * lr.grad) < (1e-5 if dtype == torch.float32 else 2 ** -7)
 
 
 def test_masked_ce_empty_mask_is_nan(ops):
     logits = torch.randn(8, 16).cuda()
     labels = torch.zeros(8, dtype=torch.long).cuda()
     mask = torch.zeros(8, dtype=torch.long).cuda()
-    loss, _ = ops.masked_ce(logits, labels, mask)
+    loss, _ = ops.masked_ce_fwd(logits, labels, mask)
     assert math.isnan(float(loss))  # reference: cross_entropy over an empty selection is NaN
 
 
