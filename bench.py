@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""Throughput of the masked-pretraining step (BASELINE.json configs[1]): 12-layer d=512 ViT over
+40x2048 synthetic uint8 lines, V=4096, bf16 MFMA, one process per GPU.
+
+  python bench.py --gpus 1 --steps 20 --warmup 5
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+      bench.py --gpus N --steps K --warmup W
+
+A step = zero_grad -> front end (u8 -> patches, mask tile) -> 12 encoder layers -> head -> masked CE ->
+backward of all of it -> [gradient all-reduce] -> fused Adam, on a batch already resident in HBM.
+Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events around every GEMM launch in
+extra (untimed-for-`value`) steps; `cpu_baseline` times the CPU oracle (oracle/pero_oracle.py, a "port")
+on the host cores for a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense, /opt/skills/guides/MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
+
+CFG = dict(num_blocks=12, model_dim=512, num_heads=4, feedforward_dim=2048, vocab=4096, width=2048, height=40,
+           patch=8, channels=3)
+
+
+def flops_per_line(c=CFG):
+    """forward F = patch + L*(qkv + attn + out + ffn) + head; step = 3F."""
+    S, d, L, ff, V = c["width"] // c["patch"], c["model_dim"], c["num_blocks"], c["feedforward_dim"], c["vocab"]
+    kp = c["channels"] * c["height"] * c["patch"]
+    F = 2 * S * kp * d + L * (2 * S * d * 3 * d + 4 * S * S * d + 2 * S * d * d + 4 * S * d * ff) + 2 * S * d * V
+    return 3 * F
+
+
+def build(device, bf16):
+    from pero_pretraining_amd.common.lr_scheduler import WarmupSchleduler
+    from pero_pretraining_amd.masked_pretraining import model as M
+    from pero_pretraining_amd.masked_pretraining.trainer import Trainer
+    from pero_pretraining_amd.optim import FusedAdam
+    torch.manual_seed(0)
+    bb = M.init_backbone({"type": "vit", "num_blocks": CFG["num_blocks"], "model_dim": CFG["model_dim"],
+                          "num_heads": CFG["num_heads"], "feedforward_dim": CFG["feedforward_dim"]})
+    hd = M.init_head({"in_features": CFG["model_dim"], "out_features": CFG["vocab"]})
+    model = M.MaskedTransformerEncoder(bb, hd).to(device).train()
+    opt = FusedAdam(model.parameters(), lr=2e-4)
+    sched = WarmupSchleduler(opt, 2e-4, 10000, 1)
+    trainer = Trainer(None, model, None, opt, sched, bfloat16=bf16)
+    return model, opt, sched, trainer
+
+
+def synthetic(rank, B, device, nbatches=2):
+    rng = np.random.default_rng(1234 + rank)
+    W, S = CFG["width"], CFG["width"] // CFG["patch"]
+    out = []
+    for _ in range(nbatches):
+        images = torch.from_numpy(rng.integers(0, 256, (B, CFG["height"], W, CFG["channels"]), dtype=np.uint8)).to(device)
+        labels = torch.from_numpy(rng.integers(0, CFG["vocab"], (B, S)).astype(np.int64)).to(device)
+        mask = torch.from_numpy((rng.random((B, S)) < 0.15).astype(np.int64)).to(device)
+        out.append((images, labels, mask))
+    return out
+
+
+def cpu_baseline(budget_s=20.0, B=4):
+    """The CPU oracle's train step (f32, torch CPU primitive ops + autograd) at the config-2 shape."""
+    from oracle import pero_oracle as O
+    from pero_pretraining_amd.masked_pretraining import model as M
+    torch.manual_seed(0)
+    bb = M.init_backbone({"type": "vit", "num_blocks": CFG["num_blocks"], "model_dim": CFG["model_dim"],
+                          "num_heads": CFG["num_heads"], "feedforward_dim": CFG["feedforward_dim"]})
+    hd = M.init_head({"in_features": CFG["model_dim"], "out_features": CFG["vocab"]})
+    sd = {k: v.clone() for k, v in M.MaskedTransformerEncoder(bb, hd).state_dict().items()}
+    orc = O.MaskedStepOracle(sd, CFG["num_heads"])
+    rng = np.random.default_rng(1234)
+    S = CFG["width"] // CFG["patch"]
+    images = rng.integers(0, 256, (B, CFG["height"], CFG["width"], CFG["channels"]), dtype=np.uint8)
+    labels = rng.integers(0, CFG["vocab"], (B, S)).astype(np.int64)
+    mask = (rng.random((B, S)) < 0.15).astype(np.int64)
+    offsets = rng.integers(0, 4096 - S, B)
+    orc.step(images, labels, mask, 2e-4, offsets)  # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        orc.step(images, labels, mask, 2e-4, offsets)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 50:
+            break
+    return {"value": round(n * B / el, 3), "unit": "lines/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} steps of B={B} lines (40x2048, 12-layer d=512, f32) through oracle/pero_oracle.py MaskedStepOracle"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("PERO_BENCH_BATCH", 64)), help="lines per GPU")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    from pero_pretraining_amd import ops
+    from pero_pretraining_amd.parallel import DataParallel
+    bf16 = args.dtype == "bf16"
+    model, opt, sched, trainer = build(device, bf16)
+    if world > 1:
+        trainer.data_parallel = DataParallel(model, opt)
+    batches = synthetic(rank, args.batch, device)
+
+    def step(i):
+        sched.update_learning_rate(i)
+        images, labels, mask = batches[i % len(batches)]
+        return trainer.train_step_prepared(images, labels, mask)
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+    final_loss = float(loss)
+
+    lines_per_s = world * args.batch * args.steps / elapsed
+    step_flops = flops_per_line()
+
+    roofline = None
+    if not args.no_roofline:
+        ops.gemm_timeline = []
+        for i in range(2):
+            step(args.warmup + args.steps + i)
+        torch.cuda.synchronize()
+        tl, ops.gemm_timeline = ops.gemm_timeline, None
+        per = {}
+        for e0, e1, fl, tag in tl:
+            d = per.setdefault(tag, [0.0, 0.0, 0])
+            d[0] += e0.elapsed_time(e1) * 1e-3
+            d[1] += fl
+            d[2] += 1
+        fast = {k: v for k, v in per.items() if k.startswith("gemm_bf16_t128")}
+        tsum = sum(v[0] for v in fast.values()) or 1e-30
+        fsum = sum(v[1] for v in fast.values())
+        nl = sum(v[2] for v in fast.values()) or 1
+        ach = fsum / tsum / 1e12
+        roofline = {"bound": "mfma", "kernel": "gemm_bf16_t128 (all operand layouts)", "achieved": round(ach, 2),
+                    "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4),
+                    "traffic": None, "launches_per_step": nl // 2, "avg_launch_us": round(tsum / nl * 1e6, 2),
+                    "gflop_per_launch": round(fsum / nl / 1e9, 3),
+                    "gemm_time_share_of_step": round((tsum / 2) / (elapsed / args.steps), 3),
+                    "by_layout": {k: {"tflops": round(v[1] / v[0] / 1e12, 1), "ms_per_step": round(v[0] / 2 * 1e3, 3),
+                                      "launches_per_step": v[2] // 2} for k, v in sorted(per.items())}}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()
+
+    if rank == 0:
+        out = {
+            "metric": "text-line images/sec (masked-ViT step)", "value": round(lines_per_s, 2), "unit": "lines/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "masked pretraining step, 12-layer d=512 h=4 ff=2048 ViT, V=4096, 40x2048 u8 lines "
+                                   "(BASELINE.json configs[1])",
+                       "lines_per_gpu": args.batch, "global_batch": args.batch * world, "seq_len": CFG["width"] // CFG["patch"],
+                       "parallelism": f"dp{world}", "optimizer": "fused Adam (f32 master weights)",
+                       "gflop_per_line_step": round(step_flops / 1e9, 3)},
+            "step_mfma_frac": round(lines_per_s / world * step_flops / (BF16_MFMA_PEAK_TFLOPS * 1e12), 4),
+            "final_loss": round(final_loss, 5),
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -54,40 +54,45 @@ __device__ __forceinline__ bf8v frag_kmajor(const unsigned char* base, int col, 
   return __builtin_bit_cast(bf8v, v);
 }
 
+// One operand tile in flight in registers: 4 x 16 bytes per thread.  Named members (not an array): an
+// array passed by reference through the load/store helpers was left in scratch memory by hipcc.
+struct Stage4 { uint4 r0, r1, r2, r3; };
+
 template <bool TR>
-__device__ __forceinline__ void stage_load(uint4 (&r)[4], const bf16raw* X, long long ld, long long tile0, long long k0, int tid) {
-  if (!TR) {  // stored [rows][K]
-    const int chunk = tid & 7;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const int row = (tid >> 3) + 32 * i;
-      r[i] = *(const uint4*)(X + (tile0 + row) * ld + k0 + chunk * 8);
-    }
-  } else {  // stored [K][rows]
-    const int c = tid & 15;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const int krow = (tid >> 4) + 16 * i;
-      r[i] = *(const uint4*)(X + (k0 + krow) * ld + tile0 + c * 8);
-    }
+__device__ __forceinline__ Stage4 stage_load(const bf16raw* X, long long ld, long long tile0, long long k0, int tid) {
+  Stage4 s;
+  if (!TR) {  // stored [rows][K]: 8 threads cover one 128-byte row segment
+    const bf16raw* p = X + (tile0 + (tid >> 3)) * ld + k0 + (tid & 7) * 8;
+    s.r0 = *(const uint4*)(p);
+    s.r1 = *(const uint4*)(p + 32 * ld);
+    s.r2 = *(const uint4*)(p + 64 * ld);
+    s.r3 = *(const uint4*)(p + 96 * ld);
+  } else {  // stored [K][rows]: 16 threads cover one 256-byte k-row segment
+    const bf16raw* p = X + (k0 + (tid >> 4)) * ld + tile0 + (tid & 15) * 8;
+    s.r0 = *(const uint4*)(p);
+    s.r1 = *(const uint4*)(p + 16 * ld);
+    s.r2 = *(const uint4*)(p + 32 * ld);
+    s.r3 = *(const uint4*)(p + 48 * ld);
   }
+  return s;
 }
 template <bool TR>
-__device__ __forceinline__ void stage_store(const uint4 (&r)[4], unsigned char* base, int tid) {
+__device__ __forceinline__ void stage_store(const Stage4& s, unsigned char* base, int tid) {
   if (!TR) {
-    const int chunk = tid & 7;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const int row = (tid >> 3) + 32 * i;
-      *(uint4*)(base + row * 128 + ((chunk ^ (row & 7)) << 4)) = r[i];
-    }
+    const int chunk = tid & 7, row = tid >> 3;  // (row + 32 i) & 7 == row & 7
+    unsigned char* p = base + row * 128 + ((chunk ^ (row & 7)) << 4);
+    *(uint4*)(p) = s.r0;
+    *(uint4*)(p + 32 * 128) = s.r1;
+    *(uint4*)(p + 64 * 128) = s.r2;
+    *(uint4*)(p + 96 * 128) = s.r3;
   } else {
-    const int c = tid & 15;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const int krow = (tid >> 4) + 16 * i;
-      *(uint4*)(base + krow * 256 + ((((c >> 1) ^ fk(krow))) << 5) + ((c & 1) << 4)) = r[i];
-    }
+    const int c = tid & 15, krow = tid >> 4;
+#define KM_OFF(kr) ((kr) * 256 + ((((c >> 1) ^ fk(kr))) << 5) + ((c & 1) << 4))
+    *(uint4*)(base + KM_OFF(krow)) = s.r0;
+    *(uint4*)(base + KM_OFF(krow + 16)) = s.r1;
+    *(uint4*)(base + KM_OFF(krow + 32)) = s.r2;
+    *(uint4*)(base + KM_OFF(krow + 48)) = s.r3;
+#undef KM_OFF
   }
 }
 
@@ -123,10 +128,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_t128(GemmP p) {
 #pragma unroll
     for (int j = 0; j < 4; j++) acc[i][j] = (f4v){0.f, 0.f, 0.f, 0.f};
 
-  uint4 ra[4], rb[4];
+  Stage4 ra, rb;
   if (nk > 0) {
-    stage_load<TA>(ra, A, p.lda, tm0, kbeg, tid);
-    stage_load<TB>(rb, B, p.ldb, tn0, kbeg, tid);
+    ra = stage_load<TA>(A, p.lda, tm0, kbeg, tid);
+    rb = stage_load<TB>(B, p.ldb, tn0, kbeg, tid);
     stage_store<TA>(ra, smem, tid);
     stage_store<TB>(rb, smem + T_OPBYTES, tid);
   }
@@ -137,8 +142,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_t128(GemmP p) {
     const unsigned char* sb = sa + T_OPBYTES;
     const bool more = (t + 1 < nk);
     if (more) {
-      stage_load<TA>(ra, A, p.lda, tm0, kbeg + (long long)(t + 1) * T_BK, tid);
-      stage_load<TB>(rb, B, p.ldb, tn0, kbeg + (long long)(t + 1) * T_BK, tid);
+      ra = stage_load<TA>(A, p.lda, tm0, kbeg + (long long)(t + 1) * T_BK, tid);
+      rb = stage_load<TB>(B, p.ldb, tn0, kbeg + (long long)(t + 1) * T_BK, tid);
     }
 #pragma unroll
     for (int ks = 0; ks < 2; ks++) {

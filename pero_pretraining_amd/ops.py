@@ -31,14 +31,27 @@ def _req_cuda(*ts):
                                     "implementation (no CPU fallback)")
 
 
+# optional launch timeline for bench.py's roofline leg: list of (start_event, end_event, flops, kernel tag)
+gemm_timeline = None
+
+
 def gemm_raw(A, B, C, M, N, K, lda, ldb, ldc, *, bias=None, residual=None, gate=None, ldr=0, ldg=0, batch=1,
              batch_inner=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), alpha=1.0, flags=0, k_split=1, in_dtype=None,
              out_dtype=None):
     """Direct pero_gemm call; A/B/C may be tensors (pointer taken at storage offset) or raw ints."""
     _req_cuda(A, B, C)
+    idt = dt(A) if in_dtype is None else in_dtype
+    if gemm_timeline is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     call("pero_gemm", ptr(A), ptr(B), ptr(C), ptr(bias), ptr(residual), ptr(gate), M, N, K, lda, ldb, ldc, ldr, ldg,
          batch, batch_inner, sA[0], sA[1], sB[0], sB[1], sC[0], sC[1], float(alpha), int(flags), int(k_split),
-         dt(A) if in_dtype is None else in_dtype, dt(C) if out_dtype is None else out_dtype, stream())
+         idt, dt(C) if out_dtype is None else out_dtype, stream())
+    if gemm_timeline is not None:
+        e1.record()
+        fast = idt == PERO_BF16 and M % 128 == 0 and N % 128 == 0 and K % 64 == 0 and not (flags & GEMM_FORCE_GENERIC)
+        lay = ("T" if flags & GEMM_TRANS_A else "N") + ("T" if flags & GEMM_TRANS_B else "N")
+        gemm_timeline.append((e0, e1, 2.0 * M * N * K * batch, ("gemm_bf16_t128" if fast else "gemm_generic") + ":" + lay))
 
 
 def gemm(a, b, out=None, *, bias=None, residual=None, gate=None, trans_a=False, trans_b=False, relu=False,

@@ -49,6 +49,12 @@ class FusedAdam(torch.optim.Optimizer):
             self._flat.append(dict(p=fp, g=fg, m=torch.zeros_like(fp), v=torch.zeros_like(fp), lp=flp, step=0,
                                    params=ps, offsets=offs))
 
+    def refresh_lowp(self):
+        """Re-cast the bf16 copies after the flat parameters were written from outside (broadcast, load)."""
+        for f in self._flat:
+            if f is not None:
+                ops.cast_to_bf16(f["p"], f["lp"])
+
     # flat views for data-parallel gradient reduction
     def flat_grads(self):
         return [f["g"] for f in self._flat if f is not None]
