@@ -46,12 +46,14 @@ int pero_abi_version(void);
  * images u8 (N,H,W,C) -> patch rows (N*S, C*H*P) ordered (c,h,p), value/255, masked patches replaced
  * by the (C,H,P) noise tile.  Replaces BatchOperator._prepare_batch_images
  * (masked_pretraining/batch_operator.py:17-20) + TransformerEncoder.mask (models/transformers.py:53-68)
- * + the im2col of Conv2d(kernel=stride=(H,P)) (models/transformers.py:99-107).  mask may be null. */
+ * + the im2col of Conv2d(kernel=stride=(H,P)) (models/transformers.py:99-107).  mask may be null.
+ * ld_out >= C*H*P is the row pitch of `patches` in elements; the padding columns are zero-filled (a pitch
+ * that is a multiple of 128 lets the weight-gradient GEMM of the patch embedding run on the fast kernel). */
 int pero_patches_from_u8(const uint8_t* images, const int64_t* mask, const float* tile, void* patches,
-                         int64_t N, int64_t H, int64_t W, int64_t C, int64_t P, int dtype, void* stream);
+                         int64_t N, int64_t H, int64_t W, int64_t C, int64_t P, int64_t ld_out, int dtype, void* stream);
 /* same from float NCHW images (the reference's own model input layout) */
 int pero_patches_from_f32(const float* images_nchw, const int64_t* mask, const float* tile, void* patches,
-                          int64_t N, int64_t H, int64_t W, int64_t C, int64_t P, int dtype, void* stream);
+                          int64_t N, int64_t H, int64_t W, int64_t C, int64_t P, int64_t ld_out, int dtype, void* stream);
 /* in-place TransformerEncoder.mask on float NCHW images (models/transformers.py:53-68) */
 int pero_apply_mask_f32(float* images_nchw, const int64_t* mask, const float* tile,
                         int64_t N, int64_t H, int64_t W, int64_t C, int64_t P, void* stream);
@@ -77,10 +79,11 @@ int pero_gemm(const void* A, const void* B, void* C, const float* bias, const vo
 int pero_layernorm_fwd(const void* x, const float* gamma, const float* beta, const float* pe, const int64_t* offsets,
                        void* y, float* mean, float* rstd, int64_t rows, int64_t d, int64_t S, float eps,
                        int dtype, void* stream);
-/* dx, and dgamma/dbeta/dxsum ACCUMULATED atomically into f32 [d] buffers (dxsum = column sums of dx,
- * i.e. the bias gradient of the Linear that produced x; may be null) */
+/* dx, and dgamma/dbeta/dxsum ACCUMULATED (+=) into f32 [d] buffers (dxsum = column sums of dx, i.e. the bias
+ * gradient of the Linear that produced x; may be null).  work: f32 workspace of 3 * PERO_LN_BWD_BLOCKS * d. */
+#define PERO_LN_BWD_BLOCKS 512
 int pero_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
-                       void* dx, float* dgamma, float* dbeta, float* dxsum, int64_t rows, int64_t d,
+                       void* dx, float* dgamma, float* dbeta, float* dxsum, float* work, int64_t rows, int64_t d,
                        int dtype, void* stream);
 
 /* ---- softmax over the last dim (attention probabilities; torch SDPA inside
@@ -109,6 +112,10 @@ int pero_colsum(const void* x, float* out, int64_t rows, int64_t cols, int64_t l
 /* f32 -> bf16 copy (low-precision weight copies) */
 int pero_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream);
 int pero_cast_bf16_f32(const void* src, float* dst, int64_t n, void* stream);
+/* dst[r][0:cols] = bf16(src[r][0:cols]), dst[r][cols:ld_dst] = 0   (K-padded low-precision weight copy) */
+int pero_cast_pad_f32_bf16(const float* src, void* dst, int64_t rows, int64_t cols, int64_t ld_dst, void* stream);
+/* dst[r][c] += src[r][c] for c < cols (f32, row pitches ld_dst / ld_src) */
+int pero_add_rows2d(float* dst, const float* src, int64_t rows, int64_t cols, int64_t ld_dst, int64_t ld_src, void* stream);
 /* y = x * scale (in place allowed), dtype elements */
 int pero_scale(void* x, int64_t n, float scale, int dtype, void* stream);
 

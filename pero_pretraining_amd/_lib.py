@@ -10,19 +10,22 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpero_hip.so")
 
 PERO_F32, PERO_BF16 = 0, 1
+LN_BWD_BLOCKS = 512
 GEMM_RELU, GEMM_ATOMIC, GEMM_ACCUM, GEMM_TRANS_A, GEMM_TRANS_B, GEMM_FORCE_GENERIC = 1, 2, 4, 8, 16, 32
 
 _vp, _i64, _i32, _f32, _f64 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_double
 
 # name -> argtypes (all functions return int unless noted)
 SIGNATURES = {
-    "pero_patches_from_u8": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i32, _vp],
-    "pero_patches_from_f32": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i32, _vp],
+    "pero_patches_from_u8": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _vp],
+    "pero_patches_from_f32": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _vp],
+    "pero_cast_pad_f32_bf16": [_vp, _vp, _i64, _i64, _i64, _vp],
+    "pero_add_rows2d": [_vp, _vp, _i64, _i64, _i64, _i64, _vp],
     "pero_apply_mask_f32": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp],
     "pero_gemm": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
                   _i64, _i64, _i64, _i64, _i64, _i64, _f32, _i32, _i32, _i32, _i32, _vp],
     "pero_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _f32, _i32, _vp],
-    "pero_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp],
+    "pero_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp],
     "pero_softmax_fwd": [_vp, _vp, _i64, _i64, _f32, _i32, _vp],
     "pero_softmax_bwd": [_vp, _vp, _vp, _i64, _i64, _f32, _i32, _vp],
     "pero_masked_ce_fwd": [_vp, _vp, _vp, _f32, _vp, _vp, _i64, _i64, _i32, _vp],

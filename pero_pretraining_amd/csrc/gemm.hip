@@ -4,8 +4,8 @@
 //
 // Two kernels:
 //  * gemm_bf16_t128: the hot kernel.  bf16 operands, f32 accumulation on
-//    v_mfma_f32_16x16x32_bf16, 128x128x64 tiles, 4 waves (2x2, 64x64 each), double-buffered LDS with
-//    register prefetch (global loads of tile t+1 are in flight while tile t is multiplied), XOR-swizzled
+//    v_mfma_f32_16x16x32_bf16, 128x128x64 tiles, 4 waves (2x2, 64x64 each), double-buffered LDS filled by
+//    LDS-DMA (global_load_lds_dwordx4: tile t+1 is in flight while tile t is multiplied), XOR-swizzled
 //    LDS images (conflict-free ds_read_b128 for K-contiguous operands, conflict-free
 //    ds_read_b64_tr_b16 for operands stored K-major), XCD-aware tile order, optional split-K with f32
 //    atomics (weight gradients: reduction over all tokens), f32 epilogue staged through LDS so that
@@ -54,46 +54,35 @@ __device__ __forceinline__ bf8v frag_kmajor(const unsigned char* base, int col, 
   return __builtin_bit_cast(bf8v, v);
 }
 
-// One operand tile in flight in registers: 4 x 16 bytes per thread.  Named members (not an array): an
-// array passed by reference through the load/store helpers was left in scratch memory by hipcc.
-struct Stage4 { uint4 r0, r1, r2, r3; };
-
+// Global -> LDS staging by LDS-DMA (global_load_lds_dwordx4): no staging VGPRs, no ds_write traffic (register
+// staging of a 128x128x64 step costs ~415 LDS cycles of ds_write_b128 against 512 MFMA cycles).  One wave
+// instruction writes 1 KiB linearly (wave base + lane * 16), so the XOR swizzles of the two LDS images are
+// applied to the per-lane SOURCE address instead (guide rule 21): piece (i, wave) covers image bytes
+// [i*4096 + wave*1024, +1024) = rows 32i + 8*wave .. +7 of a K-contiguous image, or k-rows 16i + 4*wave .. +3
+// of a K-major image, exactly the rows thread `tid` addresses below.
 template <bool TR>
-__device__ __forceinline__ Stage4 stage_load(const bf16raw* X, long long ld, long long tile0, long long k0, int tid) {
-  Stage4 s;
-  if (!TR) {  // stored [rows][K]: 8 threads cover one 128-byte row segment
-    const bf16raw* p = X + (tile0 + (tid >> 3)) * ld + k0 + (tid & 7) * 8;
-    s.r0 = *(const uint4*)(p);
-    s.r1 = *(const uint4*)(p + 32 * ld);
-    s.r2 = *(const uint4*)(p + 64 * ld);
-    s.r3 = *(const uint4*)(p + 96 * ld);
-  } else {  // stored [K][rows]: 16 threads cover one 256-byte k-row segment
-    const bf16raw* p = X + (k0 + (tid >> 4)) * ld + tile0 + (tid & 15) * 8;
-    s.r0 = *(const uint4*)(p);
-    s.r1 = *(const uint4*)(p + 16 * ld);
-    s.r2 = *(const uint4*)(p + 32 * ld);
-    s.r3 = *(const uint4*)(p + 48 * ld);
+__device__ __forceinline__ void stage_glds(const bf16raw* X, long long ld, long long tile0, long long k0,
+                                           unsigned char* lds_base, int tid) {
+  const bf16raw* p;
+  long long step;
+  if (!TR) {  // stored [rows][K]: lane's LDS slot (tid & 7) of row (tid >> 3) holds logical chunk slot ^ (row & 7)
+    const int row = tid >> 3, chunk = (tid & 7) ^ (row & 7);
+    p = X + (tile0 + row) * ld + k0 + chunk * 8;
+    step = 32 * ld;
+  } else {    // stored [K][rows]: 32-byte blocks of k-row XORed with fk(krow)
+    const int krow = tid >> 4, slot = tid & 15;
+    const int chunk = ((((slot >> 1) ^ fk(krow))) << 1) | (slot & 1);
+    p = X + (k0 + krow) * ld + tile0 + chunk * 8;
+    step = 16 * ld;
   }
-  return s;
-}
-template <bool TR>
-__device__ __forceinline__ void stage_store(const Stage4& s, unsigned char* base, int tid) {
-  if (!TR) {
-    const int chunk = tid & 7, row = tid >> 3;  // (row + 32 i) & 7 == row & 7
-    unsigned char* p = base + row * 128 + ((chunk ^ (row & 7)) << 4);
-    *(uint4*)(p) = s.r0;
-    *(uint4*)(p + 32 * 128) = s.r1;
-    *(uint4*)(p + 64 * 128) = s.r2;
-    *(uint4*)(p + 96 * 128) = s.r3;
-  } else {
-    const int c = tid & 15, krow = tid >> 4;
-#define KM_OFF(kr) ((kr) * 256 + ((((c >> 1) ^ fk(kr))) << 5) + ((c & 1) << 4))
-    *(uint4*)(base + KM_OFF(krow)) = s.r0;
-    *(uint4*)(base + KM_OFF(krow + 16)) = s.r1;
-    *(uint4*)(base + KM_OFF(krow + 32)) = s.r2;
-    *(uint4*)(base + KM_OFF(krow + 48)) = s.r3;
-#undef KM_OFF
-  }
+  unsigned char* dst = lds_base + (tid >> 6) * 1024;
+#define GLDS16(src_, dst_) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_), \
+                                                            (__attribute__((address_space(3))) void*)(dst_), 16, 0, 0)
+  GLDS16(p, dst);
+  GLDS16(p + step, dst + 4096);
+  GLDS16(p + 2 * step, dst + 8192);
+  GLDS16(p + 3 * step, dst + 12288);
+#undef GLDS16
 }
 
 template <bool TA, bool TB, bool OUTF32>
@@ -128,22 +117,21 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_t128(GemmP p) {
 #pragma unroll
     for (int j = 0; j < 4; j++) acc[i][j] = (f4v){0.f, 0.f, 0.f, 0.f};
 
-  Stage4 ra, rb;
   if (nk > 0) {
-    ra = stage_load<TA>(A, p.lda, tm0, kbeg, tid);
-    rb = stage_load<TB>(B, p.ldb, tn0, kbeg, tid);
-    stage_store<TA>(ra, smem, tid);
-    stage_store<TB>(rb, smem + T_OPBYTES, tid);
+    stage_glds<TA>(A, p.lda, tm0, kbeg, smem, tid);
+    stage_glds<TB>(B, p.ldb, tn0, kbeg, smem + T_OPBYTES, tid);
   }
-  __syncthreads();
-
   for (int t = 0; t < nk; t++) {
+    // tile t has landed (own DMA drained, then barrier: everyone's); all waves are past their reads of the
+    // other buffer (tile t-1), so it can be refilled while tile t is multiplied
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     const unsigned char* sa = smem + (t & 1) * T_BUFBYTES;
     const unsigned char* sb = sa + T_OPBYTES;
-    const bool more = (t + 1 < nk);
-    if (more) {
-      ra = stage_load<TA>(A, p.lda, tm0, kbeg + (long long)(t + 1) * T_BK, tid);
-      rb = stage_load<TB>(B, p.ldb, tn0, kbeg + (long long)(t + 1) * T_BK, tid);
+    if (t + 1 < nk) {
+      unsigned char* da = smem + ((t + 1) & 1) * T_BUFBYTES;
+      stage_glds<TA>(A, p.lda, tm0, kbeg + (long long)(t + 1) * T_BK, da, tid);
+      stage_glds<TB>(B, p.ldb, tn0, kbeg + (long long)(t + 1) * T_BK, da + T_OPBYTES, tid);
     }
 #pragma unroll
     for (int ks = 0; ks < 2; ks++) {
@@ -159,13 +147,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_t128(GemmP p) {
         for (int j = 0; j < 4; j++)  // swapped operands: D[n][m], so a lane holds 4 consecutive n of one m
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
     }
-    if (more) {
-      unsigned char* da = smem + ((t + 1) & 1) * T_BUFBYTES;
-      stage_store<TA>(ra, da, tid);
-      stage_store<TB>(rb, da + T_OPBYTES, tid);
-    }
-    __syncthreads();
   }
+  __syncthreads();  // all fragment reads done before the epilogue reuses the LDS
 
   // ---- epilogue: accumulators -> LDS (f32) -> coalesced global rows ---------------------------------
 #pragma unroll

@@ -9,7 +9,7 @@
 #define PT_TOK 16
 template <typename T>
 __global__ __launch_bounds__(256) void patches_u8_k(const uint8_t* img, const int64_t* mask, const float* tile, T* out,
-                                                    int H, int W, int C, int P, int S) {
+                                                    int H, int W, int C, int P, int S, int ldo) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int n = blockIdx.y, s0 = blockIdx.x * PT_TOK;
   const int ntok = (S - s0) < PT_TOK ? (S - s0) : PT_TOK;
@@ -36,20 +36,27 @@ __global__ __launch_bounds__(256) void patches_u8_k(const uint8_t* img, const in
     const int tok = gidx / (C * H), ch = gidx - tok * (C * H);
     const int c = ch / H, h = ch - c * H;
     const bool masked = mask && mask[(long long)n * S + s0 + tok] == 1;
-    T* o = out + ((long long)n * S + s0 + tok) * pd + (long long)ch * P;
+    T* o = out + ((long long)n * S + s0 + tok) * ldo + (long long)ch * P;
     for (int e = 0; e < P; e++) {
       const float v = masked ? tile[ch * P + e] : (float)lds[h * ldsp + (tok * P + e) * C + c] / 255.0f;
       Elem<T>::st(o + e, v);
     }
   }
+  for (int i = threadIdx.x; i < ntok * (ldo - pd); i += 256) {  // zero the row padding (GEMM-friendly pitch)
+    const int tok = i / (ldo - pd), e = i - tok * (ldo - pd);
+    Elem<T>::st(out + ((long long)n * S + s0 + tok) * ldo + pd + e, 0.f);
+  }
 }
 template <typename T>
 __global__ __launch_bounds__(256) void patches_f32_k(const float* img, const int64_t* mask, const float* tile, T* out,
-                                                     long long total, int H, int W, int C, int P, int S) {
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;  // index over (n, s, c, h, p)
+                                                     long long total, int H, int W, int C, int P, int S, int ldo) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;  // index over (token row, padded column)
   if (i >= total) return;
-  const int p = (int)(i % P);
-  long long r = i / P;
+  const int colp = (int)(i % ldo);
+  const long long tokrow = i / ldo;
+  if (colp >= C * H * P) { Elem<T>::st(out + i, 0.f); return; }
+  const int p = colp % P;
+  long long r = tokrow * (C * H) + colp / P;
   const int h = (int)(r % H); r /= H;
   const int c = (int)(r % C); r /= C;
   const int s = (int)(r % S);
@@ -57,6 +64,18 @@ __global__ __launch_bounds__(256) void patches_f32_k(const float* img, const int
   const bool masked = mask && mask[n * S + s] == 1;
   const float v = masked ? tile[(c * H + h) * P + p] : img[((n * C + c) * H + h) * W + (long long)s * P + p];
   Elem<T>::st(out + i, v);
+}
+__global__ __launch_bounds__(256) void add_rows2d_k(float* dst, const float* src, long long rows, long long cols, long long ldd, long long lds) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * cols) return;
+  const long long r = i / cols, c = i - r * cols;
+  dst[r * ldd + c] += src[r * lds + c];
+}
+__global__ __launch_bounds__(256) void cast_pad_k(const float* src, bf16raw* dst, long long rows, long long cols, long long ldd) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * ldd) return;
+  const long long r = i / ldd, c = i - r * ldd;
+  dst[i] = c < cols ? f2bf(src[r * cols + c]) : (bf16raw)0;
 }
 __global__ __launch_bounds__(256) void apply_mask_k(float* img, const int64_t* mask, const float* tile, long long total,
                                                     int H, int W, int C, int P) {
@@ -71,27 +90,28 @@ __global__ __launch_bounds__(256) void apply_mask_k(float* img, const int64_t* m
 }
 
 extern "C" int pero_patches_from_u8(const uint8_t* images, const int64_t* mask, const float* tile, void* patches,
-                                    int64_t N, int64_t H, int64_t W, int64_t C, int64_t P, int dtype, void* stream) {
+                                    int64_t N, int64_t H, int64_t W, int64_t C, int64_t P, int64_t ld_out, int dtype, void* stream) {
   PERO_REQUIRE(images && patches && (tile || !mask), "pero_patches_from_u8: null pointer");
+  PERO_REQUIRE(ld_out >= C * H * P, "pero_patches_from_u8: ld_out < C*H*P");
   PERO_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && P > 0 && W % P == 0 && N < 65536, "pero_patches_from_u8: bad sizes (W %% P must be 0)");
   const int S = (int)(W / P);
   const size_t lds = (size_t)H * PT_TOK * P * C;
   PERO_REQUIRE(lds <= 65536, "pero_patches_from_u8: H*16*P*C = %zu bytes exceeds the LDS staging budget", lds);
   dim3 grid((unsigned)((S + PT_TOK - 1) / PT_TOK), (unsigned)N), block(256);
-  if (dtype == PERO_F32) hipLaunchKernelGGL((patches_u8_k<float>), grid, block, lds, (hipStream_t)stream, images, mask, tile, (float*)patches, (int)H, (int)W, (int)C, (int)P, S);
-  else if (dtype == PERO_BF16) hipLaunchKernelGGL((patches_u8_k<bf16raw>), grid, block, lds, (hipStream_t)stream, images, mask, tile, (bf16raw*)patches, (int)H, (int)W, (int)C, (int)P, S);
+  if (dtype == PERO_F32) hipLaunchKernelGGL((patches_u8_k<float>), grid, block, lds, (hipStream_t)stream, images, mask, tile, (float*)patches, (int)H, (int)W, (int)C, (int)P, S, (int)ld_out);
+  else if (dtype == PERO_BF16) hipLaunchKernelGGL((patches_u8_k<bf16raw>), grid, block, lds, (hipStream_t)stream, images, mask, tile, (bf16raw*)patches, (int)H, (int)W, (int)C, (int)P, S, (int)ld_out);
   else PERO_REQUIRE(false, "pero_patches_from_u8: bad dtype");
   PERO_CHECK_LAUNCH("pero_patches_from_u8");
   return PERO_OK;
 }
 extern "C" int pero_patches_from_f32(const float* images, const int64_t* mask, const float* tile, void* patches,
-                                     int64_t N, int64_t H, int64_t W, int64_t C, int64_t P, int dtype, void* stream) {
+                                     int64_t N, int64_t H, int64_t W, int64_t C, int64_t P, int64_t ld_out, int dtype, void* stream) {
   PERO_REQUIRE(images && patches && (tile || !mask), "pero_patches_from_f32: null pointer");
-  PERO_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && P > 0 && W % P == 0, "pero_patches_from_f32: bad sizes");
-  const long long total = (long long)N * C * H * W;
+  PERO_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && P > 0 && W % P == 0 && ld_out >= C * H * P, "pero_patches_from_f32: bad sizes");
+  const long long total = (long long)N * (W / P) * ld_out;
   dim3 grid((unsigned)((total + 255) / 256)), block(256);
-  if (dtype == PERO_F32) hipLaunchKernelGGL((patches_f32_k<float>), grid, block, 0, (hipStream_t)stream, images, mask, tile, (float*)patches, total, (int)H, (int)W, (int)C, (int)P, (int)(W / P));
-  else if (dtype == PERO_BF16) hipLaunchKernelGGL((patches_f32_k<bf16raw>), grid, block, 0, (hipStream_t)stream, images, mask, tile, (bf16raw*)patches, total, (int)H, (int)W, (int)C, (int)P, (int)(W / P));
+  if (dtype == PERO_F32) hipLaunchKernelGGL((patches_f32_k<float>), grid, block, 0, (hipStream_t)stream, images, mask, tile, (float*)patches, total, (int)H, (int)W, (int)C, (int)P, (int)(W / P), (int)ld_out);
+  else if (dtype == PERO_BF16) hipLaunchKernelGGL((patches_f32_k<bf16raw>), grid, block, 0, (hipStream_t)stream, images, mask, tile, (bf16raw*)patches, total, (int)H, (int)W, (int)C, (int)P, (int)(W / P), (int)ld_out);
   else PERO_REQUIRE(false, "pero_patches_from_f32: bad dtype");
   PERO_CHECK_LAUNCH("pero_patches_from_f32");
   return PERO_OK;
@@ -141,6 +161,18 @@ extern "C" int pero_cast_f32_bf16(const float* src, void* dst, int64_t n, void* 
   PERO_REQUIRE(src && dst && n > 0 && aligned16(src) && aligned16(dst), "pero_cast_f32_bf16: bad arguments");
   hipLaunchKernelGGL(cast_f32_bf16_k, dim3(grid_for(n, 8)), dim3(256), 0, (hipStream_t)stream, src, (bf16raw*)dst, (long long)n);
   PERO_CHECK_LAUNCH("pero_cast_f32_bf16");
+  return PERO_OK;
+}
+extern "C" int pero_cast_pad_f32_bf16(const float* src, void* dst, int64_t rows, int64_t cols, int64_t ld_dst, void* stream) {
+  PERO_REQUIRE(src && dst && rows > 0 && cols > 0 && ld_dst >= cols, "pero_cast_pad_f32_bf16: bad arguments");
+  hipLaunchKernelGGL(cast_pad_k, dim3((unsigned)((rows * ld_dst + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, (bf16raw*)dst, (long long)rows, (long long)cols, (long long)ld_dst);
+  PERO_CHECK_LAUNCH("pero_cast_pad_f32_bf16");
+  return PERO_OK;
+}
+extern "C" int pero_add_rows2d(float* dst, const float* src, int64_t rows, int64_t cols, int64_t ld_dst, int64_t ld_src, void* stream) {
+  PERO_REQUIRE(dst && src && rows > 0 && cols > 0 && ld_dst >= cols && ld_src >= cols, "pero_add_rows2d: bad arguments");
+  hipLaunchKernelGGL(add_rows2d_k, dim3((unsigned)((rows * cols + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dst, src, (long long)rows, (long long)cols, (long long)ld_dst, (long long)ld_src);
+  PERO_CHECK_LAUNCH("pero_add_rows2d");
   return PERO_OK;
 }
 extern "C" int pero_cast_bf16_f32(const void* src, float* dst, int64_t n, void* stream) {

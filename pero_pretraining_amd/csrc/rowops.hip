@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_k(const T* x, const float* 
 // a wave visits, combined across the block's 4 waves through LDS, then one f32 atomic per column.
 template <typename T, int NCH>
 __global__ __launch_bounds__(256) void layernorm_bwd_k(const T* dy, const T* x, const float* mean, const float* rstd,
-                                                       const float* gamma, T* dx, float* dgamma, float* dbeta, float* dxsum,
+                                                       const float* gamma, T* dx, float* work, const float* dxsum,
                                                        long long rows, int d) {
   __shared__ float red[4][NCH * 512];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -133,7 +133,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_k(const T* dy, const T* x, 
       }
     }
   }
-  // three rounds (dgamma, dbeta, dxsum) through one 4 x d LDS slab
+  // per-block partial sums -> workspace [3][gridDim.x][d]; a second kernel adds them to the gradients
+  // (no contended atomics: 512 blocks adding into the same d addresses ran at ~1/14 of the atomic rate)
 #pragma unroll
   for (int which = 0; which < 3; which++) {
     if (which == 2 && !dxsum) break;
@@ -145,11 +146,37 @@ __global__ __launch_bounds__(256) void layernorm_bwd_k(const T* dy, const T* x, 
         red[wave][col] = which == 0 ? ag[c][e] : (which == 1 ? ab[c][e] : ax[c][e]);
       }
     __syncthreads();
-    float* dst = which == 0 ? dgamma : (which == 1 ? dbeta : dxsum);
+    float* dst = work + ((long long)which * gridDim.x + blockIdx.x) * d;
     for (int col = threadIdx.x; col < d; col += 256)
-      atomicAdd(dst + col, (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]));
+      dst[col] = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
     __syncthreads();
   }
+}
+__global__ __launch_bounds__(256) void layernorm_bwd_reduce_k(const float* work, float* dgamma, float* dbeta, float* dxsum,
+                                                              int nblocks, int d) {
+  // block = 64 columns x 4 slices of the partial-sum rows; 8 independent loads in flight per thread
+  __shared__ float red[4][64];
+  const int c = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + c;
+  const int which = blockIdx.y;
+  float* dst = which == 0 ? dgamma : (which == 1 ? dbeta : dxsum);
+  if (!dst) return;
+  float s = 0.f;
+  if (col < d) {
+    const float* w = work + (long long)which * nblocks * d + col;
+    const int per = (nblocks + 3) / 4, b0 = part * per, b1 = (b0 + per) < nblocks ? (b0 + per) : nblocks;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int b = b0;
+    for (; b + 8 <= b1; b += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; u++) acc[u] += w[(long long)(b + u) * d];
+    }
+    for (; b < b1; b++) acc[0] += w[(long long)b * d];
+    s = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+  }
+  red[part][c] = s;
+  __syncthreads();
+  if (part == 0 && col < d) dst[col] += (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
 }
 
 template <typename T>
@@ -164,14 +191,15 @@ static int ln_dispatch_fwd(const void* x, const float* gamma, const float* beta,
 }
 template <typename T>
 static int ln_dispatch_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma, void* dx,
-                           float* dgamma, float* dbeta, float* dxsum, int64_t rows, int64_t d, hipStream_t st) {
+                           float* dgamma, float* dbeta, float* dxsum, float* work, int64_t rows, int64_t d, hipStream_t st) {
   long long blocks = (rows + 3) / 4;
-  if (blocks > 1024) blocks = 1024;
+  if (blocks > PERO_LN_BWD_BLOCKS) blocks = PERO_LN_BWD_BLOCKS;
   dim3 grid((unsigned)blocks), block(256);
   const int nch = (int)((d + 511) / 512);
-#define LN_B(N_) hipLaunchKernelGGL((layernorm_bwd_k<T, N_>), grid, block, 0, st, (const T*)dy, (const T*)x, mean, rstd, gamma, (T*)dx, dgamma, dbeta, dxsum, (long long)rows, (int)d)
+#define LN_B(N_) hipLaunchKernelGGL((layernorm_bwd_k<T, N_>), grid, block, 0, st, (const T*)dy, (const T*)x, mean, rstd, gamma, (T*)dx, work, dxsum, (long long)rows, (int)d)
   if (nch == 1) LN_B(1); else if (nch == 2) LN_B(2); else LN_B(4);
 #undef LN_B
+  hipLaunchKernelGGL(layernorm_bwd_reduce_k, dim3((unsigned)((d + 63) / 64), 3), dim3(256), 0, st, work, dgamma, dbeta, dxsum, (int)blocks, (int)d);
   return 0;
 }
 
@@ -190,13 +218,13 @@ extern "C" int pero_layernorm_fwd(const void* x, const float* gamma, const float
 }
 
 extern "C" int pero_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
-                                  void* dx, float* dgamma, float* dbeta, float* dxsum, int64_t rows, int64_t d, int dtype,
-                                  void* stream) {
-  PERO_REQUIRE(dy && x && mean && rstd && gamma && dx && dgamma && dbeta, "pero_layernorm_bwd: null pointer");
+                                  void* dx, float* dgamma, float* dbeta, float* dxsum, float* work, int64_t rows, int64_t d,
+                                  int dtype, void* stream) {
+  PERO_REQUIRE(dy && x && mean && rstd && gamma && dx && dgamma && dbeta && work, "pero_layernorm_bwd: null pointer");
   PERO_REQUIRE(rows > 0 && d > 0 && d % 8 == 0 && d <= 2048, "pero_layernorm_bwd: need d %% 8 == 0 and d <= 2048 (d=%lld)", (long long)d);
   PERO_REQUIRE(aligned16(dy) && aligned16(x) && aligned16(dx) && aligned16(gamma), "pero_layernorm_bwd: 16-byte alignment");
-  if (dtype == PERO_F32) ln_dispatch_bwd<float>(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, dxsum, rows, d, (hipStream_t)stream);
-  else if (dtype == PERO_BF16) ln_dispatch_bwd<bf16raw>(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, dxsum, rows, d, (hipStream_t)stream);
+  if (dtype == PERO_F32) ln_dispatch_bwd<float>(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, dxsum, work, rows, d, (hipStream_t)stream);
+  else if (dtype == PERO_BF16) ln_dispatch_bwd<bf16raw>(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, dxsum, work, rows, d, (hipStream_t)stream);
   else PERO_REQUIRE(false, "pero_layernorm_bwd: bad dtype");
   PERO_CHECK_LAUNCH("pero_layernorm_bwd");
   return PERO_OK;
@@ -372,6 +400,36 @@ extern "C" int pero_masked_ce_bwd(const void* logits, const int64_t* labels, con
 // ---------------------------------------------------------------------------------------------
 // column sums: out[n] += sum_m x[m][n]
 // ---------------------------------------------------------------------------------------------
+// fast path: cols % 8 == 0, 16-byte aligned rows.  Block = 32 column groups (8 cols each) x 8 row lanes over a
+// 128-row slab; LDS combine of the 8 row lanes; one atomic per column per slab.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum8_k(const T* x, float* out, long long rows, long long cols, long long ld) {
+  __shared__ float red[8][256 + 8];
+  const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const long long col = ((long long)blockIdx.x * 32 + cg) * 8;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (col < cols) {
+    const long long r0 = (long long)blockIdx.y * 128;
+    const long long r1 = r0 + 128 < rows ? r0 + 128 : rows;
+    for (long long r = r0 + rl; r < r1; r += 8) {
+      float v[8];
+      load8<T>(x + r * ld + col, v);
+#pragma unroll
+      for (int e = 0; e < 8; e++) acc[e] += v[e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; e++) red[rl][cg * 8 + e] = acc[e];
+  __syncthreads();
+  const int c = threadIdx.x;
+  const long long gc = (long long)blockIdx.x * 256 + c;
+  if (gc < cols) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; k++) s += red[k][c];
+    atomicAdd(out + gc, s);
+  }
+}
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_k(const T* x, float* out, long long rows, long long cols, long long ld) {
   const long long col = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -382,6 +440,15 @@ __global__ __launch_bounds__(256) void colsum_k(const T* x, float* out, long lon
 }
 extern "C" int pero_colsum(const void* x, float* out, int64_t rows, int64_t cols, int64_t ld, int dtype, void* stream) {
   PERO_REQUIRE(x && out && rows > 0 && cols > 0 && ld >= cols, "pero_colsum: bad arguments");
+  const int esz = dtype == PERO_F32 ? 4 : 2;
+  if (cols % 8 == 0 && (ld * esz) % 16 == 0 && aligned16(x) && (rows + 127) / 128 < 65536) {
+    dim3 grid((unsigned)((cols + 255) / 256), (unsigned)((rows + 127) / 128)), block(256);
+    if (dtype == PERO_F32) hipLaunchKernelGGL((colsum8_k<float>), grid, block, 0, (hipStream_t)stream, (const float*)x, out, (long long)rows, (long long)cols, (long long)ld);
+    else if (dtype == PERO_BF16) hipLaunchKernelGGL((colsum8_k<bf16raw>), grid, block, 0, (hipStream_t)stream, (const bf16raw*)x, out, (long long)rows, (long long)cols, (long long)ld);
+    else PERO_REQUIRE(false, "pero_colsum: bad dtype");
+    PERO_CHECK_LAUNCH("pero_colsum");
+    return PERO_OK;
+  }
   long long gy = rows < 128 ? rows : 128;
   dim3 grid((unsigned)((cols + 255) / 256), (unsigned)gy), block(256);
   if (dtype == PERO_F32) hipLaunchKernelGGL((colsum_k<float>), grid, block, 0, (hipStream_t)stream, (const float*)x, out, (long long)rows, (long long)cols, (long long)ld);

@@ -128,18 +128,22 @@ def backbone_fwd(mod, x, mask, offsets, dtype, save):
     tile = mod.mask_tile_device(x.device)
     if mask is not None:
         mask = torch.as_tensor(mask).to(device=x.device, dtype=torch.int64).contiguous()
+    d = mod.model_dim
+    kp = mod.conv_layer.weight[0].numel()                      # C*H*P = 960
+    # bf16 path: pad the patch rows to a pitch that is a multiple of 128 so that the patch-embedding weight
+    # gradient (an N = C*H*P GEMM) runs on the fast tile kernel; the pad columns are zeros
+    pitch = kp if dtype == torch.float32 else ((kp + 127) // 128) * 128
     if x.dtype == torch.uint8:
         n, _, w, _ = x.shape
-        a0 = ops.patches_from_u8(x.contiguous(), mask, tile, P, dtype)
+        a0 = ops.patches_from_u8(x.contiguous(), mask, tile, P, dtype, pitch)
     else:
         n, _, _, w = x.shape
         xc = x.detach()
         if xc.dtype != torch.float32 or not xc.is_contiguous():
             xc = xc.float().contiguous()
-        a0 = ops.patches_from_f32(xc, mask, tile, P, dtype)
+        a0 = ops.patches_from_f32(xc, mask, tile, P, dtype, pitch)
     s = w // P
-    d = mod.model_dim
-    y0 = ops.gemm(a0, lowp.weight(mod.conv_layer.weight, dtype).view(d, -1), bias=mod.conv_layer.bias.detach())
+    y0 = ops.gemm(a0[:, :kp], lowp.weight(mod.conv_layer.weight, dtype).view(d, -1), bias=mod.conv_layer.bias.detach())
     pe = mod.position_model.pe_table(x.device)
     t, mean0, rstd0 = ops.layernorm_fwd(y0, mod.intermediate_norm.weight.detach(), mod.intermediate_norm.bias.detach(),
                                         mod.intermediate_norm.eps, pe=pe, offsets=offsets, S=s)
@@ -162,6 +166,13 @@ def backbone_bwd(mod, saved, dt, dtype, on_layer_done=None):
     nrm = mod.intermediate_norm
     dy0 = ops.layernorm_bwd(dt, y0, mean0, rstd0, nrm.weight.detach(), ensure_grad(nrm.weight), ensure_grad(nrm.bias),
                             ensure_grad(mod.conv_layer.bias))
-    linear_bwd(dy0, a0, mod.conv_layer.weight, mod.conv_layer.bias, dtype, need_dx=False, bias_grad_done=True)
+    cw = mod.conv_layer.weight
+    kp = cw[0].numel()
+    if a0.shape[1] == kp:
+        linear_bwd(dy0, a0, cw, mod.conv_layer.bias, dtype, need_dx=False, bias_grad_done=True)
+    elif cw.requires_grad:  # padded pitch: dW into a (d, pitch) scratch, then add the real columns into .grad
+        tmp = torch.zeros((cw.shape[0], a0.shape[1]), device=a0.device, dtype=torch.float32)
+        ops.gemm(dy0, a0, out=tmp, trans_a=True, trans_b=True, atomic=True, k_split=_ksplit(dy0.shape[0], tmp.numel()))
+        ops.add_rows2d(ensure_grad(cw).view(cw.shape[0], kp), tmp, kp)
     if on_layer_done is not None:
         on_layer_done(-1)

@@ -87,8 +87,9 @@ def layernorm_fwd(x, gamma, beta, eps, pe=None, offsets=None, S=1):
 def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, dxsum=None):
     rows, d = x.shape
     dx = torch.empty_like(x)
+    work = torch.empty(3 * _lib.LN_BWD_BLOCKS * d, device=x.device, dtype=torch.float32)
     call("pero_layernorm_bwd", ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(dx), ptr(dgamma), ptr(dbeta),
-         ptr(dxsum), rows, d, dt(x), stream())
+         ptr(dxsum), ptr(work), rows, d, dt(x), stream())
     return dx
 
 
@@ -141,22 +142,37 @@ def scale_(x, s):
     return x
 
 
-def patches_from_u8(images, mask, tile, P, dtype):
+def patches_from_u8(images, mask, tile, P, dtype, pitch=None):
+    """(N*S, pitch) buffer whose first C*H*P columns are the patch rows (rest zero)."""
     _req_cuda(images)
     images = images.contiguous()
     N, H, W, C = images.shape
-    out = torch.empty((N * (W // P), C * H * P), device=images.device, dtype=dtype)
-    call("pero_patches_from_u8", ptr(images), ptr(mask), ptr(tile), ptr(out), N, H, W, C, P, dt(dtype), stream())
+    pitch = pitch or C * H * P
+    out = torch.empty((N * (W // P), pitch), device=images.device, dtype=dtype)
+    call("pero_patches_from_u8", ptr(images), ptr(mask), ptr(tile), ptr(out), N, H, W, C, P, pitch, dt(dtype), stream())
     return out
 
 
-def patches_from_f32(images, mask, tile, P, dtype):
+def patches_from_f32(images, mask, tile, P, dtype, pitch=None):
     _req_cuda(images)
     images = images.contiguous()
     N, C, H, W = images.shape
-    out = torch.empty((N * (W // P), C * H * P), device=images.device, dtype=dtype)
-    call("pero_patches_from_f32", ptr(images), ptr(mask), ptr(tile), ptr(out), N, H, W, C, P, dt(dtype), stream())
+    pitch = pitch or C * H * P
+    out = torch.empty((N * (W // P), pitch), device=images.device, dtype=dtype)
+    call("pero_patches_from_f32", ptr(images), ptr(mask), ptr(tile), ptr(out), N, H, W, C, P, pitch, dt(dtype), stream())
     return out
+
+
+def cast_pad_to_bf16(src2d, pitch):
+    rows, cols = src2d.shape
+    dst = torch.empty((rows, pitch), device=src2d.device, dtype=torch.bfloat16)
+    call("pero_cast_pad_f32_bf16", ptr(src2d), ptr(dst), rows, cols, pitch, stream())
+    return dst
+
+
+def add_rows2d(dst2d, src2d, cols):
+    call("pero_add_rows2d", ptr(dst2d), ptr(src2d), dst2d.shape[0], cols, dst2d.stride(0), src2d.stride(0), stream())
+    return dst2d
 
 
 def apply_mask_(images, mask, tile, P):

@@ -252,6 +252,10 @@ def test_patches(ops, dtype, N, W):
     assert torch.equal(out2.cpu(), ref.to(dtype))
     out3 = ops.patches_from_u8(dev(images), None, None, 8, torch.float32)
     assert torch.equal(out3.cpu(), O.patches(x))
+    outp = ops.patches_from_u8(dev(images), dev(mask), dev(tile), 8, dtype, pitch=1024)
+    assert torch.equal(outp[:, :960].cpu(), ref.to(dtype)) and float(outp[:, 960:].float().abs().sum()) == 0
+    outp = ops.patches_from_f32(dev(x), dev(mask), dev(tile), 8, dtype, pitch=1024)
+    assert torch.equal(outp[:, :960].cpu(), ref.to(dtype)) and float(outp[:, 960:].float().abs().sum()) == 0
     xm = dev(x.contiguous())
     ops.apply_mask_(xm, dev(mask), dev(tile), 8)
     assert torch.equal(xm.cpu(), O.apply_mask(x, mask, tile))

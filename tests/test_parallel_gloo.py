@@ -1,0 +1,126 @@
+"""CPU, world_size 2 over gloo: the data-parallel driver (shard ranges, bucket plan, bucketed all-reduce of the
+flat gradient buffer, parameter broadcast, mean via the optimizer's grad_scale)."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from pero_pretraining_amd.parallel import DataParallel, plan_buckets, shard_range
+
+
+def test_shard_range_covers_everything():
+    for n in (0, 1, 7, 64, 4097):
+        for w in (1, 2, 3, 8):
+            spans = [shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(e - b for b, e in spans) - min(e - b for b, e in spans) <= 1
+
+
+class _Layer(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.w = torch.nn.Parameter(torch.zeros(5, 3))
+        self.b = torch.nn.Parameter(torch.zeros(5))
+
+
+class _Backbone(torch.nn.Module):
+    def __init__(self, n):
+        super().__init__()
+        self.encoder_layers = torch.nn.Module()
+        self.encoder_layers.layers = torch.nn.ModuleList([_Layer() for _ in range(n)])
+        self.conv = torch.nn.Parameter(torch.zeros(7))
+        self._on_layer_grads_ready = None
+
+
+class _Model(torch.nn.Module):
+    def __init__(self, n=3):
+        super().__init__()
+        self.backbone = _Backbone(n)
+        self.head = torch.nn.Linear(3, 2)
+
+
+class _FlatOpt:
+    """CPU stand-in with the flat-buffer surface of optim.FusedAdam."""
+
+    def __init__(self, model):
+        ps = list(model.parameters())
+        offs, total = [], 0
+        for p in ps:
+            offs.append(total)
+            total += ((p.numel() + 7) // 8) * 8
+        self.p, self.g = torch.zeros(total), torch.zeros(total)
+        for p, o in zip(ps, offs):
+            self.p[o:o + p.numel()].copy_(p.detach().reshape(-1))
+            p.data = self.p[o:o + p.numel()].view(p.shape)
+            p.grad = self.g[o:o + p.numel()].view(p.shape)
+        self._flat = [dict(p=self.p, g=self.g)]
+        self.ps, self.offs, self.grad_scale, self.refreshed = ps, offs, 1.0, 0
+
+    def flat_grads(self):
+        return [self.g]
+
+    def param_offsets(self):
+        return {id(p): (0, o, p.numel()) for p, o in zip(self.ps, self.offs)}
+
+    def refresh_lowp(self):
+        self.refreshed += 1
+
+
+def test_bucket_plan_stages():
+    model = _Model(3)
+    opt = _FlatOpt(model)
+    plan = plan_buckets(model.named_parameters(), opt.param_offsets(), 3)
+    assert set(plan) == {0, 1, 2, -1, "head"}
+    covered = sorted(r for v in plan.values() for r in v)
+    assert covered[0][1] == 0 and covered[-1][2] == opt.g.numel()
+    assert all(a[2] == b[1] for a, b in zip(covered, covered[1:]))  # disjoint and complete
+    assert all(len(plan[i]) == 1 and plan[i][0][2] - plan[i][0][1] == 16 + 8 for i in range(3))
+
+
+def _worker(rank, world, port, overlap):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)  # different initial weights per rank: broadcast must equalise them
+    model = _Model(3)
+    with torch.no_grad():
+        for p in model.parameters():
+            p.normal_()
+    opt = _FlatOpt(model)
+    dp = DataParallel(model, opt, overlap=overlap)
+    ref = [torch.empty_like(opt.p) for _ in range(world)]
+    dist.all_gather(ref, opt.p)
+    assert all(torch.equal(ref[0], r) for r in ref) and opt.refreshed == 1
+    assert opt.grad_scale == 1.0 / world
+    # "backward": every rank fills its gradients with rank-specific values, stage by stage
+    dp.begin_backward()
+    for i, p in enumerate(model.parameters()):
+        p.grad.fill_(float(rank + 1) * (i + 1))
+    if overlap:
+        for stage in (2, 1, 0, -1):
+            model.backbone._on_layer_grads_ready(stage)
+    dp.finish_backward()
+    for i, p in enumerate(model.parameters()):
+        expect = sum(float(r + 1) * (i + 1) for r in range(world))
+        assert torch.all(p.grad == expect), (i, p.grad, expect)
+        assert torch.all(p.grad * opt.grad_scale == expect / world)
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def test_bucketed_all_reduce_world2_overlap():
+    mp.spawn(_worker, args=(2, _free_port(), True), nprocs=2, join=True)
+
+
+def test_all_reduce_world2_no_overlap():
+    mp.spawn(_worker, args=(2, _free_port(), False), nprocs=2, join=True)
