@@ -143,6 +143,42 @@ int pero_gather_rows(const void* src, const int64_t* index, void* dst, int64_t n
 int pero_scatter_add_rows(const void* src, const int64_t* index, void* dst, int64_t n_idx, int64_t d,
                           int dtype, void* stream);
 
+/* ---- joint-embedding losses (joint_embedding_pretraining/losses.py) ---------------------------------------
+ * The dense products (covariance SYRK z^T z, its backward zc @ G, per-line similarity x y^T and its backward)
+ * are pero_gemm calls; these entry points are the surrounding reductions.  `g` arguments are DEVICE f32
+ * scalars holding the upstream gradient (null = 1), so backward needs no host synchronisation. */
+/* out[0] = scale * sum_rows |x[ix[r]] - y[iy[r]]|^2   (VICReg invariance, losses.py:14-16); partial: f32 [n] */
+int pero_sqdiff_rows(const void* x, const int64_t* ix, const void* y, const int64_t* iy, float* partial, float* out,
+                     int64_t n, int64_t d, float scale, int dtype, void* stream);
+/* dx[ix[r]] += g*coef*(x-y) ; dy[iy[r]] -= g*coef*(x-y) */
+int pero_sqdiff_rows_bwd(const void* x, const int64_t* ix, const void* y, const int64_t* iy, void* dx, void* dy,
+                         const float* g, float coef, int64_t n, int64_t d, int dtype, void* stream);
+/* out[0] = scale * sum(partial[0..n)) in a fixed order */
+int pero_sum_scale(const float* partial, float* out, int64_t n, float scale, void* stream);
+/* zc = z - colsum/m for rows < m, 0 for padding rows m..m_pad; sumsq[c] += sum_r zc[r][c]^2 (losses.py:38,41) */
+int pero_center_cols(const void* z, const float* colsum, void* zc, float* sumsq, int64_t m, int64_t m_pad, int64_t d,
+                     int dtype, void* stream);
+/* variance hinge loss_var = mean_j relu(threshold - sqrt(sumsq_j/(m-1) + eps)) and its per-column gradient
+ * coefficient cvar_j (losses.py:37-38) */
+int pero_vicreg_var(const float* sumsq, float* cvar, float* loss_var, int64_t m, int64_t d, float threshold, float eps,
+                    void* stream);
+/* loss_cov = sum_{i!=j} cov_ij^2 / d (losses.py:40-47) and the backward operand G (dtype, d x d):
+ * G_ij = wc*4*cov_ij/(d*(m-1)) (i != j), G_jj = wv*cvar_j, so that d(wv*var + wc*cov)/d zc = zc @ G.
+ * rowpart: f32 [d] scratch */
+int pero_vicreg_cov(const float* cov, const float* cvar, void* G, float* rowpart, float* loss_cov, int64_t d, int64_t m,
+                    float wv, float wc, int dtype, void* stream);
+/* dst[index[i]] += g * src[i] */
+int pero_scatter_add_rows_scaled(const void* src, const int64_t* index, void* dst, const float* g, int64_t n, int64_t d,
+                                 int dtype, void* stream);
+/* xn = x / max(|x|_2, 1e-12) per row, inv[r] = 1 / max(|x_r|, 1e-12)   (F.normalize, losses.py:58-59) */
+int pero_rownorm_fwd(const void* x, void* xn, float* inv, int64_t rows, int64_t d, int dtype, void* stream);
+int pero_rownorm_bwd(const void* xn, const void* dxn, const float* inv, const float* g, void* dx, int64_t rows, int64_t d,
+                     int dtype, void* stream);
+/* sim (lines, S, S) f32: line_loss[l] = mean_j (logsumexp_r sim[l][r][j] - sim[l][j][j]) (losses.py:80, softmax over
+ * dim 0), loss_out[0] = mean_l line_loss[l]; dsim (dtype, may be null) = d loss_out / d sim */
+int pero_ntxent_cols(const float* sim, float* line_loss, float* loss_out, void* dsim, int64_t lines, int64_t S, int dtype,
+                     void* stream);
+
 #ifdef __cplusplus
 }
 #endif

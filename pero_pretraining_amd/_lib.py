@@ -39,6 +39,16 @@ SIGNATURES = {
     "pero_vq_gather": [_vp, _vp, _vp, _vp, _i64, _i64, _vp],
     "pero_gather_rows": [_vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp],
     "pero_scatter_add_rows": [_vp, _vp, _vp, _i64, _i64, _i32, _vp],
+    "pero_sqdiff_rows": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _f32, _i32, _vp],
+    "pero_sqdiff_rows_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _i64, _i64, _i32, _vp],
+    "pero_sum_scale": [_vp, _vp, _i64, _f32, _vp],
+    "pero_center_cols": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp],
+    "pero_vicreg_var": [_vp, _vp, _vp, _i64, _i64, _f32, _f32, _vp],
+    "pero_vicreg_cov": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _f32, _f32, _i32, _vp],
+    "pero_scatter_add_rows_scaled": [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp],
+    "pero_rownorm_fwd": [_vp, _vp, _vp, _i64, _i64, _i32, _vp],
+    "pero_rownorm_bwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp],
+    "pero_ntxent_cols": [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp],
 }
 
 

@@ -1,0 +1,286 @@
+// Reduction kernels of the joint-embedding losses (joint_embedding_pretraining/losses.py of the reference).
+// The dense contractions (VICReg covariance SYRK, its backward, the per-line NT-Xent similarity matrices and
+// their backward products) run on pero_gemm; everything here is HBM-bound row/column work in f32 statistics.
+#include "common.hpp"
+
+// --------------------------------------------------------------------------------------------
+// squared-difference sum of gathered rows (VICReg invariance, losses.py:14-16):
+//   partial[row] = sum_c (x[ix[row]][c] - y[iy[row]][c])^2      (one wave per row, deterministic)
+// --------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void sqdiff_rows_k(const T* x, const int64_t* ix, const T* y, const int64_t* iy, float* partial,
+                                                     long long n, int d) {
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const T* a = x + ix[row] * d;
+  const T* b = y + iy[row] * d;
+  float s = 0.f;
+  for (int c = threadIdx.x & 63; c < d; c += 64) { const float t = Elem<T>::ld(a + c) - Elem<T>::ld(b + c); s += t * t; }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) partial[row] = s;
+}
+// out[0] = scale * sum(partial[0..n))  (single block, fixed order)
+__global__ __launch_bounds__(256) void sum_scale_k(const float* partial, float* out, long long n, float scale) {
+  __shared__ float sm[4];
+  float s = 0.f;
+  for (long long i = threadIdx.x; i < n; i += 256) s += partial[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = ((sm[0] + sm[1]) + (sm[2] + sm[3])) * scale;
+}
+// dx[ix[row]] += g*coef*(x-y), dy[iy[row]] -= g*coef*(x-y)   (rows of ix / iy are unique)
+template <typename T>
+__global__ __launch_bounds__(256) void sqdiff_rows_bwd_k(const T* x, const int64_t* ix, const T* y, const int64_t* iy, T* dx, T* dy,
+                                                         const float* g, float coef, long long n, int d) {
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const float c0 = coef * (g ? g[0] : 1.f);
+  const long long ra = ix[row], rb = iy[row];
+  for (int c = threadIdx.x & 63; c < d; c += 64) {
+    const float t = c0 * (Elem<T>::ld(x + ra * d + c) - Elem<T>::ld(y + rb * d + c));
+    Elem<T>::st(dx + ra * d + c, Elem<T>::ld(dx + ra * d + c) + t);
+    Elem<T>::st(dy + rb * d + c, Elem<T>::ld(dy + rb * d + c) - t);
+  }
+}
+
+// --------------------------------------------------------------------------------------------
+// VICReg statistics (losses.py:37-47).  z: (m_pad, d) gathered rows, rows >= m are zero padding.
+// center: zc = z - mean (padding rows stay 0), sumsq[c] += sum_rows zc^2.   colsum (= m * mean) is an input.
+// --------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void center_cols_k(const T* z, const float* colsum, T* zc, float* sumsq, long long m, long long m_pad, int d) {
+  __shared__ float red[8][256 + 8];
+  const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const long long col = ((long long)blockIdx.x * 32 + cg) * 8;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (col < d) {
+    float mu[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) mu[e] = colsum[col + e] / (float)m;
+    const long long r0 = (long long)blockIdx.y * 128;
+    const long long r1 = r0 + 128 < m_pad ? r0 + 128 : m_pad;
+    for (long long r = r0 + rl; r < r1; r += 8) {
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        float v = 0.f;
+        if (r < m) { v = Elem<T>::ld(z + r * d + col + e) - mu[e]; }
+        Elem<T>::st(zc + r * d + col + e, v);
+        acc[e] += v * v;
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; e++) red[rl][cg * 8 + e] = acc[e];
+  __syncthreads();
+  const int c = threadIdx.x;
+  const long long gc = (long long)blockIdx.x * 256 + c;
+  if (gc < d) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; k++) s += red[k][c];
+    atomicAdd(sumsq + gc, s);
+  }
+}
+// variance hinge (losses.py:37-38) + the per-column coefficient of its gradient:
+//   std_j = sqrt(sumsq_j/(m-1) + eps); loss_var = mean_j relu(thr - std_j);  cvar_j = std_j < thr ? -1/(d*std_j*(m-1)) : 0
+__global__ __launch_bounds__(256) void vicreg_var_k(const float* sumsq, float* cvar, float* loss_var, long long m, int d, float thr, float eps) {
+  __shared__ float sm[4];
+  float s = 0.f;
+  for (int j = threadIdx.x; j < d; j += 256) {
+    const float sd = sqrtf(sumsq[j] / (float)(m - 1) + eps);
+    const float h = thr - sd;
+    s += h > 0.f ? h : 0.f;
+    cvar[j] = h > 0.f ? -1.0f / ((float)d * sd * (float)(m - 1)) : 0.f;
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) loss_var[0] = ((sm[0] + sm[1]) + (sm[2] + sm[3])) / (float)d;
+}
+// One pass over cov (d x d, f32): row partial sums of the squared off-diagonal entries, and the backward
+// operand G (compute dtype):  G_ij = wc * 4 * cov_ij / (d * (m-1))  (i != j),  G_jj = wv * cvar_j,
+// so that d loss / d zc = zc @ G  (cov symmetric; centring backward vanishes because columns of zc sum to 0).
+template <typename T>
+__global__ __launch_bounds__(256) void vicreg_cov_k(const float* cov, const float* cvar, T* G, float* rowpart, int d, long long m,
+                                                    float wv, float wc) {
+  __shared__ float sm[4];
+  const int i = blockIdx.x;
+  const float a = wc * 4.0f / ((float)d * (float)(m - 1));
+  float s = 0.f;
+  for (int j = threadIdx.x; j < d; j += 256) {
+    const float c = cov[(long long)i * d + j];
+    if (j != i) { s += c * c; Elem<T>::st(G + (long long)i * d + j, a * c); }
+    else Elem<T>::st(G + (long long)i * d + j, wv * cvar[i]);
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) rowpart[i] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+// dst[index[i]] += g * src[i]
+template <typename T>
+__global__ __launch_bounds__(256) void scatter_add_scaled_k(const T* src, const int64_t* index, T* dst, const float* g, long long n, int d) {
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const float gs = g ? g[0] : 1.f;
+  T* o = dst + index[row] * d;
+  for (int c = threadIdx.x & 63; c < d; c += 64) Elem<T>::st(o + c, Elem<T>::ld(o + c) + gs * Elem<T>::ld(src + row * d + c));
+}
+
+// --------------------------------------------------------------------------------------------
+// NT-Xent (losses.py:56-83): L2 row normalisation and the column-normalised softmax-CE of per-line S x S
+// similarity matrices.
+// --------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void rownorm_fwd_k(const T* x, T* xn, float* inv, long long rows, int d) {
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float s = 0.f;
+  for (int c = threadIdx.x & 63; c < d; c += 64) { const float v = Elem<T>::ld(x + row * d + c); s += v * v; }
+  s = wave_sum(s);
+  const float r = 1.0f / fmaxf(sqrtf(s), 1e-12f);  // F.normalize eps
+  if ((threadIdx.x & 63) == 0) inv[row] = r;
+  for (int c = threadIdx.x & 63; c < d; c += 64) Elem<T>::st(xn + row * d + c, Elem<T>::ld(x + row * d + c) * r);
+}
+// dx = (dxn - xn * <xn, dxn>) * inv
+template <typename T>
+__global__ __launch_bounds__(256) void rownorm_bwd_k(const T* xn, const T* dxn, const float* inv, const float* g, T* dx, long long rows, int d) {
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float s = 0.f;
+  for (int c = threadIdx.x & 63; c < d; c += 64) s += Elem<T>::ld(xn + row * d + c) * Elem<T>::ld(dxn + row * d + c);
+  s = wave_sum(s);
+  const float r = inv[row] * (g ? g[0] : 1.f);
+  for (int c = threadIdx.x & 63; c < d; c += 64)
+    Elem<T>::st(dx + row * d + c, (Elem<T>::ld(dxn + row * d + c) - Elem<T>::ld(xn + row * d + c) * s) * r);
+}
+// sim: (lines, S, S) f32.  One block per line; thread = column j: lse_j = log sum_r exp(sim[r][j]);
+// line_loss = mean_j (lse_j - sim[j][j]);   dsim[r][j] = (exp(sim[r][j] - lse_j) - [r==j]) / (S * lines)
+template <typename T>
+__global__ __launch_bounds__(256) void ntxent_cols_k(const float* sim, float* line_loss, T* dsim, int S, int lines) {
+  __shared__ float sm[4];
+  const float* s = sim + (long long)blockIdx.x * S * S;
+  float acc = 0.f;
+  for (int j = threadIdx.x; j < S; j += 256) {
+    float mx = -INFINITY;
+    for (int r = 0; r < S; r++) mx = fmaxf(mx, s[(long long)r * S + j]);
+    float sum = 0.f;
+    for (int r = 0; r < S; r++) sum += expf(s[(long long)r * S + j] - mx);
+    const float lse = logf(sum) + mx;
+    acc += lse - s[(long long)j * S + j];
+    if (dsim) {
+      T* o = dsim + (long long)blockIdx.x * S * S;
+      const float w = 1.0f / ((float)S * (float)lines);
+      for (int r = 0; r < S; r++) Elem<T>::st(o + (long long)r * S + j, (expf(s[(long long)r * S + j] - lse) - (r == j ? 1.f : 0.f)) * w);
+    }
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) line_loss[blockIdx.x] = ((sm[0] + sm[1]) + (sm[2] + sm[3])) / (float)S;
+}
+
+#define DISPATCH_T(dtype, NAME, ...)                                                              \
+  do {                                                                                            \
+    if (dtype == PERO_F32) { NAME(float, __VA_ARGS__); }                                          \
+    else if (dtype == PERO_BF16) { NAME(bf16raw, __VA_ARGS__); }                                  \
+    else PERO_REQUIRE(false, "bad dtype");                                                        \
+  } while (0)
+
+extern "C" int pero_sqdiff_rows(const void* x, const int64_t* ix, const void* y, const int64_t* iy, float* partial, float* out,
+                                int64_t n, int64_t d, float scale, int dtype, void* stream) {
+  PERO_REQUIRE(x && y && ix && iy && partial && out && n > 0 && d > 0, "pero_sqdiff_rows: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((unsigned)((n + 3) / 4)), block(256);
+#define L_(T, ...) hipLaunchKernelGGL((sqdiff_rows_k<T>), grid, block, 0, st, (const T*)x, ix, (const T*)y, iy, partial, (long long)n, (int)d)
+  DISPATCH_T(dtype, L_, 0);
+#undef L_
+  hipLaunchKernelGGL(sum_scale_k, dim3(1), dim3(256), 0, st, partial, out, (long long)n, scale);
+  PERO_CHECK_LAUNCH("pero_sqdiff_rows");
+  return PERO_OK;
+}
+extern "C" int pero_sqdiff_rows_bwd(const void* x, const int64_t* ix, const void* y, const int64_t* iy, void* dx, void* dy,
+                                    const float* g, float coef, int64_t n, int64_t d, int dtype, void* stream) {
+  PERO_REQUIRE(x && y && ix && iy && dx && dy && n > 0 && d > 0, "pero_sqdiff_rows_bwd: bad arguments");
+  dim3 grid((unsigned)((n + 3) / 4)), block(256);
+#define L_(T, ...) hipLaunchKernelGGL((sqdiff_rows_bwd_k<T>), grid, block, 0, (hipStream_t)stream, (const T*)x, ix, (const T*)y, iy, (T*)dx, (T*)dy, g, coef, (long long)n, (int)d)
+  DISPATCH_T(dtype, L_, 0);
+#undef L_
+  PERO_CHECK_LAUNCH("pero_sqdiff_rows_bwd");
+  return PERO_OK;
+}
+extern "C" int pero_sum_scale(const float* partial, float* out, int64_t n, float scale, void* stream) {
+  PERO_REQUIRE(partial && out && n > 0, "pero_sum_scale: bad arguments");
+  hipLaunchKernelGGL(sum_scale_k, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, out, (long long)n, scale);
+  PERO_CHECK_LAUNCH("pero_sum_scale");
+  return PERO_OK;
+}
+extern "C" int pero_center_cols(const void* z, const float* colsum, void* zc, float* sumsq, int64_t m, int64_t m_pad, int64_t d,
+                                int dtype, void* stream) {
+  PERO_REQUIRE(z && colsum && zc && sumsq && m > 1 && m_pad >= m && d > 0 && d % 8 == 0, "pero_center_cols: bad arguments (d %% 8 == 0)");
+  dim3 grid((unsigned)((d + 255) / 256), (unsigned)((m_pad + 127) / 128)), block(256);
+#define L_(T, ...) hipLaunchKernelGGL((center_cols_k<T>), grid, block, 0, (hipStream_t)stream, (const T*)z, colsum, (T*)zc, sumsq, (long long)m, (long long)m_pad, (int)d)
+  DISPATCH_T(dtype, L_, 0);
+#undef L_
+  PERO_CHECK_LAUNCH("pero_center_cols");
+  return PERO_OK;
+}
+extern "C" int pero_vicreg_var(const float* sumsq, float* cvar, float* loss_var, int64_t m, int64_t d, float threshold, float eps,
+                               void* stream) {
+  PERO_REQUIRE(sumsq && cvar && loss_var && m > 1 && d > 0, "pero_vicreg_var: bad arguments");
+  hipLaunchKernelGGL(vicreg_var_k, dim3(1), dim3(256), 0, (hipStream_t)stream, sumsq, cvar, loss_var, (long long)m, (int)d, threshold, eps);
+  PERO_CHECK_LAUNCH("pero_vicreg_var");
+  return PERO_OK;
+}
+extern "C" int pero_vicreg_cov(const float* cov, const float* cvar, void* G, float* rowpart, float* loss_cov, int64_t d, int64_t m,
+                               float wv, float wc, int dtype, void* stream) {
+  PERO_REQUIRE(cov && cvar && G && rowpart && loss_cov && d > 0 && m > 1, "pero_vicreg_cov: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+#define L_(T, ...) hipLaunchKernelGGL((vicreg_cov_k<T>), dim3((unsigned)d), dim3(256), 0, st, cov, cvar, (T*)G, rowpart, (int)d, (long long)m, wv, wc)
+  DISPATCH_T(dtype, L_, 0);
+#undef L_
+  hipLaunchKernelGGL(sum_scale_k, dim3(1), dim3(256), 0, st, rowpart, loss_cov, (long long)d, 1.0f / (float)d);
+  PERO_CHECK_LAUNCH("pero_vicreg_cov");
+  return PERO_OK;
+}
+extern "C" int pero_scatter_add_rows_scaled(const void* src, const int64_t* index, void* dst, const float* g, int64_t n, int64_t d,
+                                            int dtype, void* stream) {
+  PERO_REQUIRE(src && index && dst && n > 0 && d > 0, "pero_scatter_add_rows_scaled: bad arguments");
+  dim3 grid((unsigned)((n + 3) / 4)), block(256);
+#define L_(T, ...) hipLaunchKernelGGL((scatter_add_scaled_k<T>), grid, block, 0, (hipStream_t)stream, (const T*)src, index, (T*)dst, g, (long long)n, (int)d)
+  DISPATCH_T(dtype, L_, 0);
+#undef L_
+  PERO_CHECK_LAUNCH("pero_scatter_add_rows_scaled");
+  return PERO_OK;
+}
+extern "C" int pero_rownorm_fwd(const void* x, void* xn, float* inv, int64_t rows, int64_t d, int dtype, void* stream) {
+  PERO_REQUIRE(x && xn && inv && rows > 0 && d > 0, "pero_rownorm_fwd: bad arguments");
+  dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+#define L_(T, ...) hipLaunchKernelGGL((rownorm_fwd_k<T>), grid, block, 0, (hipStream_t)stream, (const T*)x, (T*)xn, inv, (long long)rows, (int)d)
+  DISPATCH_T(dtype, L_, 0);
+#undef L_
+  PERO_CHECK_LAUNCH("pero_rownorm_fwd");
+  return PERO_OK;
+}
+extern "C" int pero_rownorm_bwd(const void* xn, const void* dxn, const float* inv, const float* g, void* dx, int64_t rows, int64_t d,
+                                int dtype, void* stream) {
+  PERO_REQUIRE(xn && dxn && inv && dx && rows > 0 && d > 0, "pero_rownorm_bwd: bad arguments");
+  dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+#define L_(T, ...) hipLaunchKernelGGL((rownorm_bwd_k<T>), grid, block, 0, (hipStream_t)stream, (const T*)xn, (const T*)dxn, inv, g, (T*)dx, (long long)rows, (int)d)
+  DISPATCH_T(dtype, L_, 0);
+#undef L_
+  PERO_CHECK_LAUNCH("pero_rownorm_bwd");
+  return PERO_OK;
+}
+extern "C" int pero_ntxent_cols(const float* sim, float* line_loss, float* loss_out, void* dsim, int64_t lines, int64_t S, int dtype,
+                                void* stream) {
+  PERO_REQUIRE(sim && line_loss && loss_out && lines > 0 && S > 0, "pero_ntxent_cols: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+#define L_(T, ...) hipLaunchKernelGGL((ntxent_cols_k<T>), dim3((unsigned)lines), dim3(256), 0, st, sim, line_loss, (T*)dsim, (int)S, (int)lines)
+  DISPATCH_T(dtype, L_, 0);
+#undef L_
+  hipLaunchKernelGGL(sum_scale_k, dim3(1), dim3(256), 0, st, line_loss, loss_out, (long long)lines, 1.0f / (float)lines);
+  PERO_CHECK_LAUNCH("pero_ntxent_cols");
+  return PERO_OK;
+}

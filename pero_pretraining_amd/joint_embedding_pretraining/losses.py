@@ -1,0 +1,136 @@
+"""VICRegLoss and NTXentLoss with the interface of the reference's joint_embedding_pretraining/losses.py,
+computed by HIP kernels: boolean-mask row selections become index gathers, the covariance (a D x D SYRK)
+and the per-line similarity matrices run on pero_gemm, the statistics are f32 reductions."""
+import torch
+
+from .. import ops
+from .._lib import GEMM_TRANS_A, GEMM_TRANS_B
+from ..precision import compute_dtype
+
+
+def _rows(t, dtype):
+    t2 = t.detach().reshape(-1, t.shape[-1])
+    if t2.dtype != dtype or not t2.is_contiguous():
+        t2 = t2.to(dtype).contiguous()
+    return t2
+
+
+def _nz(mask, value=1):
+    # index list of the selected positions (host-visible sizes: one sync per mask, like the reference's
+    # boolean indexing)
+    return torch.nonzero(mask.reshape(-1) == value, as_tuple=False).reshape(-1).contiguous()
+
+
+class _VICRegFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y, im1, im2, sm1, sm2, wv, wi, wc, thr, eps, dtype):
+        D = x.shape[-1]
+        x2, y2 = _rows(x, dtype), _rows(y, dtype)
+        ix, iy, jx, jy = _nz(sm1), _nz(sm2), _nz(im1), _nz(im2)
+        if ix.numel() != iy.numel():
+            raise RuntimeError(f"The size of tensor a ({ix.numel()}) must match the size of tensor b ({iy.numel()}) "
+                               "at non-singleton dimension 0")  # what mse_loss reports in the reference
+        n_inv = ix.numel()
+        inv = ops.sqdiff_rows(x2, ix, y2, iy, 1.0 / (n_inv * D))
+        n1, m = jx.numel(), jx.numel() + jy.numel()
+        m_pad = ((m + 63) // 64) * 64
+        z = torch.empty((m_pad, D), device=x2.device, dtype=dtype)
+        ops.gather_rows(x2, jx, out=z[:n1])
+        ops.gather_rows(y2, jy, n_rows_out=m_pad - n1, out=z[n1:])
+        cs = torch.zeros(D, device=x2.device, dtype=torch.float32)
+        ops.colsum(z, cs)
+        zc, sumsq = ops.center_cols(z, cs, m)
+        cvar, var = ops.vicreg_var(sumsq, m, thr, eps)
+        cov = ops.gemm(zc, zc, trans_a=True, trans_b=True, alpha=1.0 / (m - 1), out_dtype=torch.float32)
+        G, covl = ops.vicreg_cov(cov, cvar, m, wv, wc, dtype)
+        loss = wv * var + wi * inv + wc * covl
+        ctx.save_for_backward(x2, y2, ix, iy, jx, jy, zc, G)
+        ctx.meta = (x.shape, y.shape, n1, m, wi * 2.0 / (n_inv * D), dtype)
+        ctx.mark_non_differentiable(var, inv, covl)
+        return loss[0], var[0], inv[0], covl[0]
+
+    @staticmethod
+    def backward(ctx, g, _gv, _gi, _gc):
+        x2, y2, ix, iy, jx, jy, zc, G = ctx.saved_tensors
+        xs, ys, n1, m, inv_coef, dtype = ctx.meta
+        gdev = g.detach().reshape(1).to(torch.float32)
+        dzc = ops.gemm(zc, G)  # (m_pad, D): d(wv*var + wc*cov)/d zc
+        dx = torch.zeros_like(x2)
+        dy = torch.zeros_like(y2)
+        ops.scatter_add_rows_scaled(dzc[:n1], jx, dx, gdev)
+        ops.scatter_add_rows_scaled(dzc[n1:m], jy, dy, gdev)
+        ops.sqdiff_rows_bwd(x2, ix, y2, iy, dx, dy, gdev, inv_coef)
+        return (dx.view(xs), dy.view(ys)) + (None,) * 10
+
+
+class VICRegLoss(torch.nn.Module):
+    """joint_embedding_pretraining/losses.py:3-47."""
+
+    def __init__(self, variance_weight=1.0, invariance_weight=1.0, covariance_weight=1.0, variance_threshold=1.0):
+        super().__init__()
+        self.variance_weight = variance_weight
+        self.invariance_weight = invariance_weight
+        self.covariance_weight = covariance_weight
+        self.variance_threshold = variance_threshold
+        self.eps = 1e-5
+
+    def forward(self, x, y, image_masks1, image_masks2, shift_masks1, shift_masks2):
+        if not x.is_cuda:
+            raise RuntimeError("pero_pretraining_amd losses run on the GPU only (HIP kernels, no CPU fallback)")
+        dev = x.device
+        masks = [torch.as_tensor(m).to(dev) for m in (image_masks1, image_masks2, shift_masks1, shift_masks2)]
+        loss, var, inv, cov = _VICRegFn.apply(x, y, *masks, float(self.variance_weight), float(self.invariance_weight),
+                                              float(self.covariance_weight), float(self.variance_threshold), self.eps,
+                                              compute_dtype())
+        return {"loss": loss, "loss.variance": var, "loss.invariance": inv, "loss.covariance": cov}
+
+
+class _NTXentFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y, temperature, dtype):
+        n, s, D = x.shape
+        xn, invx = ops.rownorm_fwd(_rows(x, dtype))
+        yn, invy = ops.rownorm_fwd(_rows(y, dtype))
+        sim = torch.empty((n, s, s), device=x.device, dtype=torch.float32)
+        ops.gemm_raw(xn, yn, sim, s, s, D, D, D, s, batch=n, sA=(s * D, 0), sB=(s * D, 0), sC=(s * s, 0),
+                     alpha=1.0 / temperature)
+        loss, _, dsim = ops.ntxent_cols(sim, dtype)
+        ctx.save_for_backward(xn, yn, invx, invy, dsim)
+        ctx.meta = (x.shape, temperature)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        xn, yn, invx, invy, dsim = ctx.saved_tensors
+        (n, s, D), temperature = ctx.meta
+        gdev = g.detach().reshape(1).to(torch.float32)
+        dxn = torch.empty_like(xn)
+        dyn = torch.empty_like(yn)
+        # d xn = dsim @ yn / T ; d yn = dsim^T @ xn / T   (per line)
+        ops.gemm_raw(dsim, yn, dxn, s, D, s, s, D, D, batch=n, sA=(s * s, 0), sB=(s * D, 0), sC=(s * D, 0),
+                     alpha=1.0 / temperature, flags=GEMM_TRANS_B)
+        ops.gemm_raw(dsim, xn, dyn, s, D, s, s, D, D, batch=n, sA=(s * s, 0), sB=(s * D, 0), sC=(s * D, 0),
+                     alpha=1.0 / temperature, flags=GEMM_TRANS_A | GEMM_TRANS_B)
+        dx = ops.rownorm_bwd(xn, dxn, invx, gdev)
+        dy = ops.rownorm_bwd(yn, dyn, invy, gdev)
+        return dx.view(n, s, D), dy.view(n, s, D), None, None
+
+
+class NTXentLoss(torch.nn.Module):
+    """joint_embedding_pretraining/losses.py:51-83.  Like the reference, only all-ones masks are valid: the
+    reference indexes the shift-reduced similarity matrix with the full-length image masks (losses.py:78) and
+    raises IndexError for every other input; the same exception is raised here."""
+
+    def __init__(self, temperature=0.1):
+        super().__init__()
+        self.temperature = temperature
+
+    def forward(self, x, y, image_masks1, image_masks2, shift_masks1, shift_masks2):
+        if not x.is_cuda:
+            raise RuntimeError("pero_pretraining_amd losses run on the GPU only (HIP kernels, no CPU fallback)")
+        for m in (shift_masks1, shift_masks2, image_masks1, image_masks2):
+            mt = torch.as_tensor(m)
+            if bool((mt != 1).any()):
+                raise IndexError("The shape of the mask at index 0 does not match the shape of the indexed tensor "
+                                 "(NT-Xent of the reference is only defined for all-ones masks)")
+        return {"loss": _NTXentFn.apply(x, y, float(self.temperature), compute_dtype())}

@@ -204,11 +204,12 @@ def vq_gather(x, codebook, idx):
     return q
 
 
-def gather_rows(src, index, n_rows_out=None):
+def gather_rows(src, index, n_rows_out=None, out=None):
     n_idx = index.numel()
     n_out = n_idx if n_rows_out is None else n_rows_out
     d = src.shape[-1]
-    dst = torch.empty((n_out, d), device=src.device, dtype=src.dtype)
+    dst = torch.empty((n_out, d), device=src.device, dtype=src.dtype) if out is None else out
+    assert dst.shape == (n_out, d) and dst.is_contiguous()
     call("pero_gather_rows", ptr(src), ptr(index), ptr(dst), n_idx, n_out, d, dt(src), stream())
     return dst
 
@@ -217,3 +218,72 @@ def scatter_add_rows(src, index, dst):
     if index.numel():
         call("pero_scatter_add_rows", ptr(src), ptr(index), ptr(dst), index.numel(), dst.shape[-1], dt(src), stream())
     return dst
+
+
+# ---- joint-embedding loss reductions ----------------------------------------------------------------------
+def sqdiff_rows(x, ix, y, iy, scale):
+    n, d = ix.numel(), x.shape[-1]
+    partial = torch.empty(n, device=x.device, dtype=torch.float32)
+    out = torch.empty(1, device=x.device, dtype=torch.float32)
+    call("pero_sqdiff_rows", ptr(x), ptr(ix), ptr(y), ptr(iy), ptr(partial), ptr(out), n, d, float(scale), dt(x), stream())
+    return out
+
+
+def sqdiff_rows_bwd(x, ix, y, iy, dx, dy, g, coef):
+    call("pero_sqdiff_rows_bwd", ptr(x), ptr(ix), ptr(y), ptr(iy), ptr(dx), ptr(dy), ptr(g), float(coef), ix.numel(),
+         x.shape[-1], dt(x), stream())
+
+
+def center_cols(z, colsum_, m):
+    m_pad, d = z.shape
+    zc = torch.empty_like(z)
+    sumsq = torch.zeros(d, device=z.device, dtype=torch.float32)
+    call("pero_center_cols", ptr(z), ptr(colsum_), ptr(zc), ptr(sumsq), m, m_pad, d, dt(z), stream())
+    return zc, sumsq
+
+
+def vicreg_var(sumsq, m, threshold, eps):
+    d = sumsq.numel()
+    cvar = torch.empty(d, device=sumsq.device, dtype=torch.float32)
+    loss = torch.empty(1, device=sumsq.device, dtype=torch.float32)
+    call("pero_vicreg_var", ptr(sumsq), ptr(cvar), ptr(loss), m, d, float(threshold), float(eps), stream())
+    return cvar, loss
+
+
+def vicreg_cov(cov, cvar, m, wv, wc, dtype):
+    d = cov.shape[0]
+    G = torch.empty((d, d), device=cov.device, dtype=dtype)
+    rowpart = torch.empty(d, device=cov.device, dtype=torch.float32)
+    loss = torch.empty(1, device=cov.device, dtype=torch.float32)
+    call("pero_vicreg_cov", ptr(cov), ptr(cvar), ptr(G), ptr(rowpart), ptr(loss), d, m, float(wv), float(wc), dt(dtype), stream())
+    return G, loss
+
+
+def scatter_add_rows_scaled(src, index, dst, g):
+    if index.numel():
+        call("pero_scatter_add_rows_scaled", ptr(src), ptr(index), ptr(dst), ptr(g), index.numel(), dst.shape[-1], dt(src), stream())
+    return dst
+
+
+def rownorm_fwd(x):
+    rows, d = x.shape
+    xn = torch.empty_like(x)
+    inv = torch.empty(rows, device=x.device, dtype=torch.float32)
+    call("pero_rownorm_fwd", ptr(x), ptr(xn), ptr(inv), rows, d, dt(x), stream())
+    return xn, inv
+
+
+def rownorm_bwd(xn, dxn, inv, g=None):
+    dx = torch.empty_like(xn)
+    call("pero_rownorm_bwd", ptr(xn), ptr(dxn), ptr(inv), ptr(g), ptr(dx), xn.shape[0], xn.shape[1], dt(xn), stream())
+    return dx
+
+
+def ntxent_cols(sim, want_grad_dtype=None):
+    lines, S, _ = sim.shape
+    line_loss = torch.empty(lines, device=sim.device, dtype=torch.float32)
+    loss = torch.empty(1, device=sim.device, dtype=torch.float32)
+    dsim = torch.empty(sim.shape, device=sim.device, dtype=want_grad_dtype) if want_grad_dtype is not None else None
+    call("pero_ntxent_cols", ptr(sim), ptr(line_loss), ptr(loss), ptr(dsim), lines, S,
+         dt(want_grad_dtype) if want_grad_dtype is not None else PERO_F32, stream())
+    return loss, line_loss, dsim
