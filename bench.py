@@ -167,12 +167,12 @@ def main():
             d[0] += e0.elapsed_time(e1) * 1e-3
             d[1] += fl
             d[2] += 1
-        fast = {k: v for k, v in per.items() if k.startswith("gemm_bf16_t128")}
+        fast = {k: v for k, v in per.items() if k.startswith("gemm_bf16_tile")}
         tsum = sum(v[0] for v in fast.values()) or 1e-30
         fsum = sum(v[1] for v in fast.values())
         nl = sum(v[2] for v in fast.values()) or 1
         ach = fsum / tsum / 1e12
-        roofline = {"bound": "mfma", "kernel": "gemm_bf16_t128 (all operand layouts)", "achieved": round(ach, 2),
+        roofline = {"bound": "mfma", "kernel": "gemm_bf16_t256 / gemm_bf16_t128 (bf16 tile GEMM, all operand layouts)", "achieved": round(ach, 2),
                     "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4),
                     "traffic": None, "launches_per_step": nl // 2, "avg_launch_us": round(tsum / nl * 1e6, 2),
                     "gflop_per_launch": round(fsum / nl / 1e9, 3),

@@ -37,10 +37,15 @@ extern "C" {
 #define PERO_GEMM_ACCUM 4       /* f32 C only: C += result (non-atomic) */
 #define PERO_GEMM_TRANS_A 8     /* A is stored [K][M] (lda = row pitch of that storage) */
 #define PERO_GEMM_TRANS_B 16    /* B is stored [K][N]; default B is stored [N][K] (Linear weight layout) */
+#define PERO_GEMM_TILE128 64     /* benchmarking: force the 128x128-tile bf16 kernel */
+#define PERO_GEMM_TILE256 128    /* benchmarking: force the 256x256-tile bf16 kernel (when the shape allows) */
+#define PERO_GEMM_TILE_S 256     /* benchmarking: force the 128x128x32 four-workgroups-per-CU kernel */
 #define PERO_GEMM_FORCE_GENERIC 32 /* testing: take the exact-f32 generic kernel even when the fast bf16 kernel applies */
 
 const char* pero_last_error(void);
 int pero_abi_version(void);
+/* tuning knobs for benchmarking: "gemm_policy" = 0 auto | 1 128-tile persistent | 2 256-tile | 3 128x128x32 */
+int pero_set_option(const char* name, int value);
 
 /* ---- front end ------------------------------------------------------------------------------
  * images u8 (N,H,W,C) -> patch rows (N*S, C*H*P) ordered (c,h,p), value/255, masked patches replaced
@@ -64,7 +69,8 @@ int pero_apply_mask_f32(float* images_nchw, const int64_t* mask, const float* ti
  * models/transformers.py:37-43,99 ; masked_pretraining/model.py:102 ; models/autoencoders.py:214 ;
  * joint_embedding_pretraining/losses.py:42,77 and their autograd backward products.
  * Batch b = bo * batch_inner + bi; operand base offset = bo * s?o + bi * s?i (elements).
- * in_dtype: A, B (and residual, gate); out_dtype: C.  bias is f32.  k_split > 1 needs PERO_GEMM_ATOMIC. */
+ * in_dtype: A, B (and residual, gate); out_dtype: C.  bias is f32.  k_split > 1 needs PERO_GEMM_ATOMIC;
+ * k_split == 0 with PERO_GEMM_ATOMIC lets the library choose tile size and split. */
 int pero_gemm(const void* A, const void* B, void* C, const float* bias, const void* residual, const void* gate,
               int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int64_t ldg,
               int64_t batch, int64_t batch_inner,
@@ -93,6 +99,16 @@ int pero_softmax_fwd(const float* s, void* p, int64_t rows, int64_t cols, float 
 /* ds = scale * p * (dp - sum_j p*dp); dp is f32, p and ds have `dtype` */
 int pero_softmax_bwd(const void* p, const float* dp, void* ds, int64_t rows, int64_t cols, float scale, int dtype,
                      void* stream);
+
+/* ---- fused attention (bf16, head_dim 128, S % 128 == 0) on the packed qkv (N*S, 3*nh*128) tensor -----------------
+ * out (N*S, nh*128) = softmax(q k^T / sqrt(hd)) v per (line, head); lse (N*nh, S) f32 = base-2 log-sum-exp of the
+ * scaled scores (kept for the backward kernels).  Scores never touch memory.  Other shapes / f32: use the
+ * batched pero_gemm + pero_softmax_* path. */
+int pero_attention_fwd(const void* qkv, void* out, float* lse, int64_t N, int64_t S, int64_t num_heads,
+                       int64_t head_dim, int dtype, void* stream);
+/* dqkv (N*S, 3d) from dout (N*S, d); dvec (N*nh, S) f32 scratch (row sums of dout*out) */
+int pero_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* dvec, void* dqkv,
+                       int64_t N, int64_t S, int64_t num_heads, int64_t head_dim, int dtype, void* stream);
 
 /* ---- masked cross entropy (masked_pretraining/model.py:72-95) -------------------------------------------
  * logits (rows, V); labels, mask int64 (rows).  loss_out[0] = mean CE over mask==1 rows

@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libpero_hip.so")
 PERO_F32, PERO_BF16 = 0, 1
 LN_BWD_BLOCKS = 512
 GEMM_RELU, GEMM_ATOMIC, GEMM_ACCUM, GEMM_TRANS_A, GEMM_TRANS_B, GEMM_FORCE_GENERIC = 1, 2, 4, 8, 16, 32
+GEMM_TILE128, GEMM_TILE256 = 64, 128
 
 _vp, _i64, _i32, _f32, _f64 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_double
 
@@ -26,6 +27,8 @@ SIGNATURES = {
                   _i64, _i64, _i64, _i64, _i64, _i64, _f32, _i32, _i32, _i32, _i32, _vp],
     "pero_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _f32, _i32, _vp],
     "pero_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp],
+    "pero_attention_fwd": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp],
+    "pero_attention_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp],
     "pero_softmax_fwd": [_vp, _vp, _i64, _i64, _f32, _i32, _vp],
     "pero_softmax_bwd": [_vp, _vp, _vp, _i64, _i64, _f32, _i32, _vp],
     "pero_masked_ce_fwd": [_vp, _vp, _vp, _f32, _vp, _vp, _i64, _i64, _i32, _vp],
@@ -72,6 +75,8 @@ def lib():
         h.pero_last_error.argtypes = []
         h.pero_abi_version.restype = ctypes.c_int
         h.pero_abi_version.argtypes = []
+        h.pero_set_option.restype = ctypes.c_int
+        h.pero_set_option.argtypes = [ctypes.c_char_p, ctypes.c_int]
         for name, args in SIGNATURES.items():
             fn = getattr(h, name)
             fn.restype = ctypes.c_int

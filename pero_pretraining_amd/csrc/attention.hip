@@ -1,0 +1,414 @@
+// Fused multi-head attention for the encoder layers (torch SDPA inside TransformerEncoderLayer._sa_block,
+// reference models/transformers.py:36-43,86): softmax(q k^T / sqrt(hd)) v over all S keys of a line, no masks.
+//
+// bf16, head_dim 128, S a multiple of 128, operating directly on the packed qkv (N*S, 3d) tensor.
+//
+// Forward: one workgroup = 128 queries of one (line, head); 4 waves x 32 queries.  Keys are processed in
+// tiles of 128 (online softmax across tiles).  Everything is computed TRANSPOSED so that a query lives on a
+// LANE and keys / head-dim live on registers (guide section 3 "an accumulator tile as the next MFMA's operand"):
+//   S^T tile (32 keys x 32 q)  = mfma_32x32x16(A = K rows from LDS, B = Q^T from registers)
+//   row max / sum of a query    = in-lane reduction over its 64 score registers + ONE lane^32 exchange
+//   P^T (bf16, packed in place) = the B operand of  O^T (32 d x 32 q) += mfma(A = V^T via ds_read_b64_tr_b16, B = P^T)
+// so the probabilities never leave registers, the softmax statistics and the O rescale are lane-local, and the
+// S x S score matrix is never written to memory (the unfused path moves 6*S^2 bytes per (line, head)).
+// K and V tiles arrive by LDS-DMA; K image XOR-swizzled for conflict-free ds_read_b128 (256-byte rows), V image
+// swizzled in 64-byte blocks for conflict-free transposed reads.  2 workgroups per CU (64 KiB LDS each).
+#include "common.hpp"
+
+#define AT_TILE_BYTES (128 * 128 * 2)  // 32 KiB: 128 keys x 128 head-dim bf16
+
+// piece p (0..31) of a 128x128 bf16 tile = rows 4p..4p+3 (1 KiB); lane -> (row, 16-byte slot)
+template <bool VIMG>
+__device__ __forceinline__ void attn_glds_tile(const bf16raw* g, long long ld, unsigned char* lds, int wave, int lane) {
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const int p = wave + 4 * i;
+    const int row = 4 * p + (lane >> 4), slot = lane & 15;
+    // K image: 16-byte chunk index ^ (row & 15).  V image: 64-byte block index ^ (row & 3).
+    const int chunk = VIMG ? ((((slot >> 2) ^ (row & 3)) << 2) | (slot & 3)) : (slot ^ (row & 15));
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + (long long)row * ld + chunk * 8),
+                                     (__attribute__((address_space(3))) void*)(lds + p * 1024), 16, 0, 0);
+  }
+}
+
+__device__ __forceinline__ bf8v attn_k_frag(const unsigned char* kimg, int key, int ks, int h5) {
+  const int chunk = 2 * ks + h5;
+  return *(const bf8v*)(kimg + key * 256 + ((chunk ^ (key & 15)) << 4));
+}
+// A operand of O^T += V^T P^T for k-step (kb .. kb+15) and d-tile dt: element j <- V[kb + 8(j>>2) + 4h + (j&3)][dt*32 + (lane&31)]
+__device__ __forceinline__ bf8v attn_vT_frag(const unsigned char* vimg, int kb, int dt, int lane) {
+  const int i = lane & 15, g1 = (lane >> 4) & 1, h5 = lane >> 5;
+  const int key = kb + 4 * h5 + (i >> 2);  // (key & 3) == (i >> 2) for both reads (kb, 4*h5, +8 are multiples of 4)
+  const unsigned char* a = vimg + key * 256 + ((dt ^ (key & 3)) << 6) + g1 * 32 + (i & 3) * 8;
+  s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s4v, a));
+  s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s4v, a + 8 * 256));
+  typedef short s8v __attribute__((ext_vector_type(8)));
+  s8v v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf8v, v);
+}
+__device__ __forceinline__ bf8v pack8(const f16v& a, int s) {
+  typedef unsigned u4v __attribute__((ext_vector_type(4)));
+  u4v u = {pack2bf(a[8 * s + 0], a[8 * s + 1]), pack2bf(a[8 * s + 2], a[8 * s + 3]), pack2bf(a[8 * s + 4], a[8 * s + 5]),
+           pack2bf(a[8 * s + 6], a[8 * s + 7])};
+  return __builtin_bit_cast(bf8v, u);
+}
+
+__global__ __launch_bounds__(256, 2) void attn_fwd_k(const bf16raw* qkv, bf16raw* out, float* lse2, int S, int nh, float c) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* kimg = smem;
+  unsigned char* vimg = smem + AT_TILE_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h5 = lane >> 5, r = lane & 31;
+  const int nqb = S >> 7;
+  const int qb = blockIdx.x % nqb, lh = blockIdx.x / nqb;
+  const int line = lh / nh, head = lh % nh;
+  const long long d = (long long)nh * 128, ld = 3 * d;
+  const bf16raw* base = qkv + (long long)line * S * ld + head * 128;
+  const bf16raw* Kg = base + d;
+  const bf16raw* Vg = base + 2 * d;
+  const int q = qb * 128 + wave * 32 + r;  // this lane's query (both lane halves hold the same query)
+
+  attn_glds_tile<false>(Kg, ld, kimg, wave, lane);
+  attn_glds_tile<true>(Vg, ld, vimg, wave, lane);
+
+  bf8v qf[8];
+  {
+    const bf16raw* qrow = base + (long long)q * ld + 8 * h5;
+#pragma unroll
+    for (int ks = 0; ks < 8; ks++) qf[ks] = *(const bf8v*)(qrow + 16 * ks);
+  }
+  f16v o[4];
+#pragma unroll
+  for (int t = 0; t < 4; t++) o[t] = (f16v){0};
+  float m = -INFINITY, l = 0.f;
+  const int nkt = S >> 7;
+
+  for (int kt = 0; kt < nkt; kt++) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // K(kt), V(kt) landed
+    f16v s[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      s[t] = (f16v){0};
+#pragma unroll
+      for (int ks = 0; ks < 8; ks++)
+        s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(attn_k_frag(kimg, t * 32 + r, ks, h5), qf[ks], s[t], 0, 0, 0);
+    }
+    __syncthreads();  // every wave is done with the K image
+    if (kt + 1 < nkt) attn_glds_tile<false>(Kg + (long long)(kt + 1) * 128 * ld, ld, kimg, wave, lane);
+
+    // ---- online softmax, all lane-local except one lane^32 exchange per reduction
+    float mx = s[0][0];
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) mx = fmaxf(mx, s[t][e]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mn = fmaxf(m, mx);
+    const float alpha = __builtin_amdgcn_exp2f((m - mn) * c);  // exp2(-inf) = 0 on the first tile
+    const float mc = mn * c;
+    float ps = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) {
+        const float p = __builtin_amdgcn_exp2f(fmaf(s[t][e], c, -mc));
+        s[t][e] = p;
+        ps += p;
+      }
+    ps += __shfl_xor(ps, 32, 64);
+    l = l * alpha + ps;
+    m = mn;
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) o[t][e] *= alpha;
+
+    // ---- O^T += V^T P^T
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+#pragma unroll
+      for (int sub = 0; sub < 2; sub++) {
+        const bf8v pf = pack8(s[t], sub);
+#pragma unroll
+        for (int dt = 0; dt < 4; dt++)
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(attn_vT_frag(vimg, t * 32 + sub * 16, dt, lane), pf, o[dt], 0, 0, 0);
+      }
+    }
+    if (kt + 1 < nkt) {
+      __syncthreads();  // every wave is done with the V image
+      attn_glds_tile<true>(Vg + (long long)(kt + 1) * 128 * ld, ld, vimg, wave, lane);
+    }
+  }
+
+  // ---- epilogue: O[q][d] = o[dt][reg] / l ; d = dt*32 + (reg&3) + 8*(reg>>2) + 4*h5 : 4 consecutive d per reg group
+  const float inv = 1.0f / l;
+  bf16raw* orow = out + ((long long)line * S + q) * d + head * 128;
+#pragma unroll
+  for (int dt = 0; dt < 4; dt++)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; g4++) {
+      uint2 w;
+      w.x = pack2bf(o[dt][4 * g4 + 0] * inv, o[dt][4 * g4 + 1] * inv);
+      w.y = pack2bf(o[dt][4 * g4 + 2] * inv, o[dt][4 * g4 + 3] * inv);
+      *(uint2*)(orow + dt * 32 + 8 * g4 + 4 * h5) = w;
+    }
+  if (h5 == 0) lse2[(long long)lh * S + q] = m * c + __builtin_amdgcn_logf(l);  // base-2 log-sum-exp of c*scores
+}
+
+extern "C" int pero_attention_fwd(const void* qkv, void* out, float* lse, int64_t N, int64_t S, int64_t num_heads,
+                                  int64_t head_dim, int dtype, void* stream) {
+  PERO_REQUIRE(qkv && out && lse, "pero_attention_fwd: null pointer");
+  PERO_REQUIRE(dtype == PERO_BF16 && head_dim == 128 && S % 128 == 0 && S > 0 && N > 0 && num_heads > 0,
+               "pero_attention_fwd: fused kernel needs bf16, head_dim 128, S %% 128 == 0 (got hd=%lld S=%lld)", (long long)head_dim, (long long)S);
+  PERO_REQUIRE(aligned16(qkv) && aligned16(out), "pero_attention_fwd: 16-byte alignment");
+  static bool attr = false;
+  if (!attr) { hipFuncSetAttribute((const void*)attn_fwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * AT_TILE_BYTES); attr = true; }
+  const float c = (float)(1.4426950408889634 / sqrt((double)head_dim));
+  hipLaunchKernelGGL(attn_fwd_k, dim3((unsigned)(N * num_heads * (S / 128))), dim3(256), 2 * AT_TILE_BYTES, (hipStream_t)stream,
+                     (const bf16raw*)qkv, (bf16raw*)out, lse, (int)S, (int)num_heads, c);
+  PERO_CHECK_LAUNCH("pero_attention_fwd");
+  return PERO_OK;
+}
+
+// =================================================================================================
+// Backward.  Two kernels, each recomputing S^T / P from q, k and the saved base-2 log-sum-exp (no S x S
+// tensor is ever stored):
+//   attn_bwd_dq_k : workgroup = 128 queries of a (line, head), query on the lane, sweeps the keys in 32-key
+//                   sub-tiles: S^T = K Q^T, dP^T = V dO^T, dS^T = P^T (dP^T - D) scale, dQ^T += K^T dS^T.
+//                   Also writes D[q] = sum_d dO[q][d] O[q][d] for the second kernel.
+//   attn_bwd_dkv_k: workgroup = 128 keys, key on the lane, sweeps the queries in 32-query sub-tiles:
+//                   S = Q K^T, P, dP = dO V^T, dS; dV^T += dO^T P, dK^T += Q^T dS.
+// No atomics, deterministic; costs 7 MFMA products instead of the minimal 5 (attention is ~8 % of the step's
+// FLOPs).  All LDS tiles use ONE dual-use image (guide T10 image (b)): 256-byte rows, 16-byte chunk index XORed
+// with f(row) = ((row&3)<<2)|((row>>2)&3): conflict-free both for ds_read_b128 row reads (32x32x16 A operand)
+// and for ds_read_b64_tr_b16 transposed reads, so K (dq kernel) and Q, dO (dkv kernel) are staged once.
+// =================================================================================================
+__device__ __forceinline__ int img_f(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+
+__device__ __forceinline__ void attn_glds_img(const bf16raw* g, long long ld, unsigned char* lds, int wave, int lane) {
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const int p = wave + 4 * i;
+    const int row = 4 * p + (lane >> 4), slot = lane & 15;
+    const int chunk = slot ^ img_f(row);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + (long long)row * ld + chunk * 8),
+                                     (__attribute__((address_space(3))) void*)(lds + p * 1024), 16, 0, 0);
+  }
+}
+// A operand, row-wise: lane holds M[row][16*ks + 8*h5 .. +8]
+__device__ __forceinline__ bf8v img_row_frag(const unsigned char* img, int row, int ks, int h5) {
+  return *(const bf8v*)(img + row * 256 + (((2 * ks + h5) ^ img_f(row)) << 4));
+}
+// A operand, transposed: element j <- M[rb + 8(j>>2) + 4h + (j&3)][dt*32 + (lane&31)]   (rb multiple of 16)
+__device__ __forceinline__ bf8v img_tr_frag(const unsigned char* img, int rb, int dt, int lane) {
+  const int i = lane & 15, g1 = (lane >> 4) & 1, h5 = lane >> 5;
+  const int row = rb + 4 * h5 + (i >> 2);
+  const int ch = 4 * dt + 2 * g1 + ((i & 3) >> 1);
+  const unsigned char* a = img + row * 256 + ((ch ^ img_f(row)) << 4) + 8 * (i & 1);
+  // second read: row + 8 -> (row&3) unchanged, (row>>2)&3 flips bit 1: f(row+8) = f(row) ^ 2
+  const unsigned char* b = img + (row + 8) * 256 + ((ch ^ img_f(row + 8)) << 4) + 8 * (i & 1);
+  s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s4v, a));
+  s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s4v, b));
+  typedef short s8v __attribute__((ext_vector_type(8)));
+  s8v v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf8v, v);
+}
+
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_k(const bf16raw* qkv, const bf16raw* out, const bf16raw* dout, const float* lse2,
+                                                        float* dvec, bf16raw* dqkv, int S, int nh, float c, float scale) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* kimg = smem;
+  unsigned char* vimg = smem + AT_TILE_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h5 = lane >> 5, r = lane & 31;
+  const int nqb = S >> 7;
+  const int qb = blockIdx.x % nqb, lh = blockIdx.x / nqb;
+  const int line = lh / nh, head = lh % nh;
+  const long long d = (long long)nh * 128, ld = 3 * d;
+  const bf16raw* base = qkv + (long long)line * S * ld + head * 128;
+  const bf16raw* Kg = base + d;
+  const bf16raw* Vg = base + 2 * d;
+  const int q = qb * 128 + wave * 32 + r;
+
+  attn_glds_img(Kg, ld, kimg, wave, lane);
+  attn_glds_img(Vg, ld, vimg, wave, lane);
+
+  bf8v qf[8], gf[8];
+  float dsum = 0.f;
+  {
+    const bf16raw* qrow = base + (long long)q * ld + 8 * h5;
+    const bf16raw* grow = dout + ((long long)line * S + q) * d + head * 128 + 8 * h5;
+    const bf16raw* orow = out + ((long long)line * S + q) * d + head * 128 + 8 * h5;
+#pragma unroll
+    for (int ks = 0; ks < 8; ks++) {
+      qf[ks] = *(const bf8v*)(qrow + 16 * ks);
+      gf[ks] = *(const bf8v*)(grow + 16 * ks);
+      const bf8v of = *(const bf8v*)(orow + 16 * ks);
+#pragma unroll
+      for (int e = 0; e < 8; e++) dsum += (float)gf[ks][e] * (float)of[e];
+    }
+  }
+  dsum += __shfl_xor(dsum, 32, 64);
+  const float lq = lse2[(long long)lh * S + q];
+  if (h5 == 0) dvec[(long long)lh * S + q] = dsum;
+
+  f16v dq[4];
+#pragma unroll
+  for (int t = 0; t < 4; t++) dq[t] = (f16v){0};
+  const int nkt = S >> 7;
+  for (int kt = 0; kt < nkt; kt++) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 4; t++) {  // 32-key sub-tile
+      f16v s = {0}, dp = {0};
+#pragma unroll
+      for (int ks = 0; ks < 8; ks++) {
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_row_frag(kimg, t * 32 + r, ks, h5), qf[ks], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_row_frag(vimg, t * 32 + r, ks, h5), gf[ks], dp, 0, 0, 0);
+      }
+#pragma unroll
+      for (int e = 0; e < 16; e++) {
+        const float p = __builtin_amdgcn_exp2f(fmaf(s[e], c, -lq));
+        s[e] = p * (dp[e] - dsum) * scale;  // dS^T
+      }
+#pragma unroll
+      for (int sub = 0; sub < 2; sub++) {
+        const bf8v dsf = pack8(s, sub);
+#pragma unroll
+        for (int dt = 0; dt < 4; dt++)
+          dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_tr_frag(kimg, t * 32 + sub * 16, dt, lane), dsf, dq[dt], 0, 0, 0);
+      }
+    }
+    if (kt + 1 < nkt) {
+      __syncthreads();
+      attn_glds_img(Kg + (long long)(kt + 1) * 128 * ld, ld, kimg, wave, lane);
+      attn_glds_img(Vg + (long long)(kt + 1) * 128 * ld, ld, vimg, wave, lane);
+    }
+  }
+  bf16raw* orow = dqkv + ((long long)line * S + q) * ld + head * 128;
+#pragma unroll
+  for (int dt = 0; dt < 4; dt++)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; g4++) {
+      uint2 w;
+      w.x = pack2bf(dq[dt][4 * g4 + 0], dq[dt][4 * g4 + 1]);
+      w.y = pack2bf(dq[dt][4 * g4 + 2], dq[dt][4 * g4 + 3]);
+      *(uint2*)(orow + dt * 32 + 8 * g4 + 4 * h5) = w;
+    }
+}
+
+// ROLE 0: dV only (S, P, dV^T += dO^T P).  ROLE 1: dK only (S, P, dP, dS, dK^T += Q^T dS).  Holding both
+// accumulator sets plus both register-resident key operands in one wave needs > 256 VGPRs (spills), so the two
+// gradients are separate launches of one template.
+template <int ROLE>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_k(const bf16raw* qkv, const bf16raw* dout, const float* lse2, const float* dvec,
+                                                         bf16raw* dqkv, int S, int nh, float c, float scale) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* qimg = smem;
+  unsigned char* gimg = smem + AT_TILE_BYTES;
+  float* lds_l = (float*)(smem + 2 * AT_TILE_BYTES);  // 128 lse2 + 128 D values of the current query tile
+  float* lds_d = lds_l + 128;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h5 = lane >> 5, r = lane & 31;
+  const int nkb = S >> 7;
+  const int kb = blockIdx.x % nkb, lh = blockIdx.x / nkb;
+  const int line = lh / nh, head = lh % nh;
+  const long long d = (long long)nh * 128, ld = 3 * d;
+  const bf16raw* base = qkv + (long long)line * S * ld + head * 128;
+  const bf16raw* Gg = dout + (long long)line * S * d + head * 128;
+  const int key = kb * 128 + wave * 32 + r;
+
+  attn_glds_img(base, ld, qimg, wave, lane);
+  attn_glds_img(Gg, d, gimg, wave, lane);
+  if (tid < 128) lds_l[tid] = lse2[(long long)lh * S + tid];
+  else lds_d[tid - 128] = dvec[(long long)lh * S + tid - 128];
+
+  bf8v kf[8], vf[8];
+  {
+    const bf16raw* krow = base + d + (long long)key * ld + 8 * h5;
+    const bf16raw* vrow = base + 2 * d + (long long)key * ld + 8 * h5;
+#pragma unroll
+    for (int ks = 0; ks < 8; ks++) {
+      kf[ks] = *(const bf8v*)(krow + 16 * ks);
+      if (ROLE == 1) vf[ks] = *(const bf8v*)(vrow + 16 * ks);
+    }
+  }
+  f16v acc[4];  // dV^T (ROLE 0) or dK^T (ROLE 1): 32 d x 32 keys per tile, key on the lane
+#pragma unroll
+  for (int t = 0; t < 4; t++) acc[t] = (f16v){0};
+  const int nqt = S >> 7;
+  for (int qt = 0; qt < nqt; qt++) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 4; t++) {  // 32-query sub-tile: rows q = t*32 + (e&3) + 8(e>>2) + 4*h5 on the registers
+      f16v s = {0}, dp = {0};
+#pragma unroll
+      for (int ks = 0; ks < 8; ks++) {
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_row_frag(qimg, t * 32 + r, ks, h5), kf[ks], s, 0, 0, 0);
+        if (ROLE == 1) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_row_frag(gimg, t * 32 + r, ks, h5), vf[ks], dp, 0, 0, 0);
+      }
+#pragma unroll
+      for (int g4 = 0; g4 < 4; g4++) {
+        const f4v l4 = *(const f4v*)(lds_l + t * 32 + 8 * g4 + 4 * h5);
+        const f4v d4 = *(const f4v*)(lds_d + t * 32 + 8 * g4 + 4 * h5);
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const float p = __builtin_amdgcn_exp2f(fmaf(s[4 * g4 + e], c, -l4[e]));
+          s[4 * g4 + e] = ROLE == 0 ? p : p * (dp[4 * g4 + e] - d4[e]) * scale;  // P or dS
+        }
+      }
+      const unsigned char* timg = ROLE == 0 ? gimg : qimg;  // dV^T += dO^T P ; dK^T += Q^T dS
+#pragma unroll
+      for (int sub = 0; sub < 2; sub++) {
+        const bf8v pf = pack8(s, sub);
+#pragma unroll
+        for (int dt = 0; dt < 4; dt++)
+          acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_tr_frag(timg, t * 32 + sub * 16, dt, lane), pf, acc[dt], 0, 0, 0);
+      }
+    }
+    if (qt + 1 < nqt) {
+      __syncthreads();
+      attn_glds_img(base + (long long)(qt + 1) * 128 * ld, ld, qimg, wave, lane);
+      attn_glds_img(Gg + (long long)(qt + 1) * 128 * d, d, gimg, wave, lane);
+      if (tid < 128) lds_l[tid] = lse2[(long long)lh * S + (qt + 1) * 128 + tid];
+      else lds_d[tid - 128] = dvec[(long long)lh * S + (qt + 1) * 128 + tid - 128];
+    }
+  }
+  bf16raw* orow = dqkv + ((long long)line * S + key) * ld + (ROLE == 0 ? 2 * d : d) + head * 128;
+#pragma unroll
+  for (int dt = 0; dt < 4; dt++)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; g4++) {
+      uint2 w;
+      w.x = pack2bf(acc[dt][4 * g4 + 0], acc[dt][4 * g4 + 1]);
+      w.y = pack2bf(acc[dt][4 * g4 + 2], acc[dt][4 * g4 + 3]);
+      *(uint2*)(orow + dt * 32 + 8 * g4 + 4 * h5) = w;
+    }
+}
+
+extern "C" int pero_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* dvec, void* dqkv,
+                                  int64_t N, int64_t S, int64_t num_heads, int64_t head_dim, int dtype, void* stream) {
+  PERO_REQUIRE(qkv && out && dout && lse && dvec && dqkv, "pero_attention_bwd: null pointer");
+  PERO_REQUIRE(dtype == PERO_BF16 && head_dim == 128 && S % 128 == 0 && S > 0 && N > 0 && num_heads > 0,
+               "pero_attention_bwd: fused kernel needs bf16, head_dim 128, S %% 128 == 0");
+  PERO_REQUIRE(aligned16(qkv) && aligned16(out) && aligned16(dout) && aligned16(dqkv), "pero_attention_bwd: 16-byte alignment");
+  static bool attr = false;
+  if (!attr) {
+    hipFuncSetAttribute((const void*)attn_bwd_dq_k, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * AT_TILE_BYTES);
+    hipFuncSetAttribute((const void*)attn_bwd_dkv_k<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * AT_TILE_BYTES + 1024);
+    hipFuncSetAttribute((const void*)attn_bwd_dkv_k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * AT_TILE_BYTES + 1024);
+    attr = true;
+  }
+  const float scale = (float)(1.0 / sqrt((double)head_dim));
+  const float c = (float)(1.4426950408889634 / sqrt((double)head_dim));
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((unsigned)(N * num_heads * (S / 128))), block(256);
+  hipLaunchKernelGGL(attn_bwd_dq_k, grid, block, 2 * AT_TILE_BYTES, st, (const bf16raw*)qkv, (const bf16raw*)out, (const bf16raw*)dout, lse,
+                     dvec, (bf16raw*)dqkv, (int)S, (int)num_heads, c, scale);
+  hipLaunchKernelGGL(attn_bwd_dkv_k<0>, grid, block, 2 * AT_TILE_BYTES + 1024, st, (const bf16raw*)qkv, (const bf16raw*)dout, lse, dvec,
+                     (bf16raw*)dqkv, (int)S, (int)num_heads, c, scale);
+  hipLaunchKernelGGL(attn_bwd_dkv_k<1>, grid, block, 2 * AT_TILE_BYTES + 1024, st, (const bf16raw*)qkv, (const bf16raw*)dout, lse, dvec,
+                     (bf16raw*)dqkv, (int)S, (int)num_heads, c, scale);
+  PERO_CHECK_LAUNCH("pero_attention_bwd");
+  return PERO_OK;
+}

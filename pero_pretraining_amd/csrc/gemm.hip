@@ -14,13 +14,8 @@
 //    fmaf chain).  Parity mode (PERO_F32), ragged shapes and small problems.
 #include "common.hpp"
 
-struct GemmP {
-  const void* A; const void* B; void* C;
-  const float* bias; const void* resid; const void* gate;
-  long long M, N, K, lda, ldb, ldc, ldr, ldg;
-  long long sAo, sAi, sBo, sBi, sCo, sCi;
-  int binner; float alpha; int flags; long long kchunk;
-};
+#include "gemm_common.hpp"
+#include <string.h>
 
 // ------------------------------------------------------------------------------------------------
 // fast bf16 kernel
@@ -32,8 +27,6 @@ struct GemmP {
 #define T_BUFBYTES (2 * T_OPBYTES)        // A + B
 #define T_EPI_PITCH 528                   // f32 epilogue row pitch in bytes (128*4 + 16)
 #define T_LDS_BYTES (128 * T_EPI_PITCH)   // 67584 >= 2 * T_BUFBYTES (65536)
-
-__device__ __forceinline__ int fk(int krow) { return (krow & 3) | (((krow >> 3) & 1) << 2); }
 
 // K-contiguous image [128 rows][64 k] (128-byte rows), 16-byte chunk index XORed with (row & 7)
 __device__ __forceinline__ bf8v frag_rowmajor(const unsigned char* base, int row, int ks, int lane) {
@@ -85,148 +78,218 @@ __device__ __forceinline__ void stage_glds(const bf16raw* X, long long ld, long 
 #undef GLDS16
 }
 
+// Persistent tile loop: 2 workgroups per CU walk the work items (tile, batch, k-slice); the LDS-DMA of the NEXT
+// item's first k-tile is issued before the current item's epilogue, and the epilogue stores straight from the
+// accumulators (a lane owns 4 consecutive output columns), so its HBM writes drain while the next main loop runs.
+// Measured before this change (M=32768, N=2048, K=512): loads 35 us + MFMA 42 us + epilogue 35 us ran almost
+// serially (100 us); K=512 GEMMs with bf16 output sit at the ridge of the HBM-write and MFMA rooflines, so the
+// three phases must overlap.  vmcnt counts stores too: the wait for the prefetched tile is a COUNTED vmcnt that
+// leaves the epilogue's stores in flight, and barriers are raw s_barrier (a __syncthreads would drain vmcnt(0)).
+struct WorkItem { long long tm0, tn0, kbeg; int nk; const bf16raw* A; const bf16raw* B; long long coff; };
+
+__device__ __forceinline__ WorkItem work_item(const GemmP& p, long long w, int ntn, int nt, int nbatch) {
+  WorkItem it;
+  const int lin = (int)(w % nt);
+  const long long rest = w / nt;
+  const int b = (int)(rest % nbatch), z = (int)(rest / nbatch);
+  // XCD-aware tile order (blocks b, b+8, ... share an XCD): each XCD gets a contiguous run of tiles, N fastest
+  const int q = nt >> 3, r8 = nt & 7, xcd = lin & 7, loc = lin >> 3;
+  const int id = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + loc;
+  it.tm0 = (long long)(id / ntn) * T_BM;
+  it.tn0 = (long long)(id % ntn) * T_BN;
+  const long long bo = b / p.binner, bi = b % p.binner;
+  it.A = (const bf16raw*)p.A + bo * p.sAo + bi * p.sAi;
+  it.B = (const bf16raw*)p.B + bo * p.sBo + bi * p.sBi;
+  it.coff = bo * p.sCo + bi * p.sCi;
+  it.kbeg = (long long)z * p.kchunk;
+  long long kend = it.kbeg + p.kchunk;
+  if (kend > p.K) kend = p.K;
+  it.nk = (int)((kend - it.kbeg) / T_BK);
+  return it;
+}
+
+// Direct epilogue of one 16x16 accumulator block: lane -> row m, 4 consecutive columns n..n+3.
+template <bool OUTF32>
+__device__ __forceinline__ void store_block(const GemmP& p, const f4v& a, long long coff, long long m, long long n) {
+  float v[4];
+  f4v bias = {0.f, 0.f, 0.f, 0.f};
+  if (p.bias) bias = *(const f4v*)(p.bias + n);
+#pragma unroll
+  for (int e = 0; e < 4; e++) v[e] = a[e] * p.alpha + bias[e];
+  if (p.resid) {
+    const uint2 rr = *(const uint2*)((const bf16raw*)p.resid + coff + m * p.ldr + n);
+    v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
+    v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
+  }
+  if (p.flags & PERO_GEMM_RELU) {
+#pragma unroll
+    for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.f);
+  }
+  if (p.gate) {
+    const uint2 gg = *(const uint2*)((const bf16raw*)p.gate + coff + m * p.ldg + n);
+    if (!(__uint_as_float(gg.x << 16) > 0.f)) v[0] = 0.f;
+    if (!(__uint_as_float(gg.x & 0xffff0000u) > 0.f)) v[1] = 0.f;
+    if (!(__uint_as_float(gg.y << 16) > 0.f)) v[2] = 0.f;
+    if (!(__uint_as_float(gg.y & 0xffff0000u) > 0.f)) v[3] = 0.f;
+  }
+  if (OUTF32) {
+    float* C = (float*)p.C + coff + m * p.ldc + n;
+    if (p.flags & PERO_GEMM_ACCUM) {
+      const f4v o = *(const f4v*)C;
+#pragma unroll
+      for (int e = 0; e < 4; e++) v[e] += o[e];
+    }
+    *(f4v*)C = (f4v){v[0], v[1], v[2], v[3]};
+  } else {
+    uint2 o;
+    o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
+    *(uint2*)((bf16raw*)p.C + coff + m * p.ldc + n) = o;
+  }
+}
+
+// Persistent tile loop with a DEFERRED epilogue.  vmcnt counts loads, LDS-DMA and stores in issue order, so a
+// wave that has just issued a tile's 16 stores cannot wait for its next LDS-DMA without also waiting for those
+// stores to reach HBM (measured: the 134 MB output of a 32768 x 2048 x 512 GEMM cost 30 us on top of the 73 us main
+// loop, fully exposed, for 128- and 256-wide tiles alike).  Instead the finished accumulators are kept in registers
+// and their stores are issued two blocks per k-step INSIDE the next work item's main loop, right after that
+// k-step's wait: by the next wait (one k-step of MFMAs later) they have drained.  The next item's first k-tile is
+// prefetched by LDS-DMA during the last k-step of the current one.  2 workgroups per CU walk the items.
 template <bool TA, bool TB, bool OUTF32>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_t128(GemmP p) {
+__global__ __launch_bounds__(256, 2) void gemm_bf16_t128(GemmP p, int nbatch, long long nwork) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-
-  // XCD-aware tile order: blocks b, b+8, ... share an XCD (and its L2); give each XCD a contiguous
-  // run of tiles (N fastest) so that neighbours share the A row panel.  Bijective for any tile count.
   const int ntn = (int)(p.N / T_BN);
   const int nt = (int)(p.M / T_BM) * ntn;
-  const int bid = blockIdx.x;
-  const int q = nt >> 3, r8 = nt & 7, xcd = bid & 7, loc = bid >> 3;
-  const int id = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + loc;
-  const long long tm0 = (long long)(id / ntn) * T_BM, tn0 = (long long)(id % ntn) * T_BN;
+  const bool atomic = OUTF32 && (p.flags & PERO_GEMM_ATOMIC);
+  const int lm = wm * 64 + (lane & 15), ln = wn * 64 + (lane >> 4) * 4;  // lane's row / first column inside a tile
 
-  const int b = blockIdx.y;
-  const long long bo = b / p.binner, bi = b % p.binner;
-  const bf16raw* A = (const bf16raw*)p.A + bo * p.sAo + bi * p.sAi;
-  const bf16raw* B = (const bf16raw*)p.B + bo * p.sBo + bi * p.sBi;
-  const long long coff = bo * p.sCo + bi * p.sCi;
+  long long w = blockIdx.x;
+  if (w >= nwork) return;
+  WorkItem it = work_item(p, w, ntn, nt, nbatch);
+  int buf = 0;  // LDS buffer holding the current k-tile
+  stage_glds<TA>(it.A, p.lda, it.tm0, it.kbeg, smem, tid);
+  stage_glds<TB>(it.B, p.ldb, it.tn0, it.kbeg, smem + T_OPBYTES, tid);
 
-  const long long kbeg = (long long)blockIdx.z * p.kchunk;
-  long long kend = kbeg + p.kchunk;
-  if (kend > p.K) kend = p.K;
-  const int nk = (int)((kend - kbeg) / T_BK);
+  f4v prev[4][4];  // finished tile awaiting its stores
+  bool have_prev = false;
+  long long pm = 0, pn = 0, pcoff = 0;
+#define STORE_PREV(I_, J_) store_block<OUTF32>(p, prev[I_][J_], pcoff, pm + (I_) * 16, pn + (J_) * 16)
+#define STORE_PREV_BATCH(B_)                                                        \
+  do { STORE_PREV((2 * (B_)) & 3, (2 * (B_)) >> 2); STORE_PREV((2 * (B_) + 1) & 3, (2 * (B_) + 1) >> 2); } while (0)
 
-  f4v acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; i++)
-#pragma unroll
-    for (int j = 0; j < 4; j++) acc[i][j] = (f4v){0.f, 0.f, 0.f, 0.f};
+  while (true) {
+    const long long wnext = w + gridDim.x;
+    const bool have_next = wnext < nwork;
+    WorkItem nx;
+    if (have_next) nx = work_item(p, wnext, ntn, nt, nbatch);
 
-  if (nk > 0) {
-    stage_glds<TA>(A, p.lda, tm0, kbeg, smem, tid);
-    stage_glds<TB>(B, p.ldb, tn0, kbeg, smem + T_OPBYTES, tid);
-  }
-  for (int t = 0; t < nk; t++) {
-    // tile t has landed (own DMA drained, then barrier: everyone's); all waves are past their reads of the
-    // other buffer (tile t-1), so it can be refilled while tile t is multiplied
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    const unsigned char* sa = smem + (t & 1) * T_BUFBYTES;
-    const unsigned char* sb = sa + T_OPBYTES;
-    if (t + 1 < nk) {
-      unsigned char* da = smem + ((t + 1) & 1) * T_BUFBYTES;
-      stage_glds<TA>(A, p.lda, tm0, kbeg + (long long)(t + 1) * T_BK, da, tid);
-      stage_glds<TB>(B, p.ldb, tn0, kbeg + (long long)(t + 1) * T_BK, da + T_OPBYTES, tid);
-    }
+    f4v acc[4][4];
 #pragma unroll
-    for (int ks = 0; ks < 2; ks++) {
-      bf8v fa[4], fb[4];
+    for (int i = 0; i < 4; i++)
 #pragma unroll
-      for (int i = 0; i < 4; i++) {
-        fa[i] = TA ? frag_kmajor(sa, wm * 64 + i * 16, ks, lane) : frag_rowmajor(sa, wm * 64 + i * 16, ks, lane);
-        fb[i] = TB ? frag_kmajor(sb, wn * 64 + i * 16, ks, lane) : frag_rowmajor(sb, wn * 64 + i * 16, ks, lane);
+      for (int j = 0; j < 4; j++) acc[i][j] = (f4v){0.f, 0.f, 0.f, 0.f};
+
+    for (int t = 0; t < it.nk; t++) {
+      // k-tile t has landed (own DMA drained; the <= 2 store blocks issued one k-step ago drained with it), the
+      // barrier publishes everyone's pieces and retires all reads of the other buffer
+      wait_vmcnt<0>();
+      lds_barrier();
+      if (have_prev) {
+        switch (t) {
+          case 0: STORE_PREV_BATCH(0); break;
+          case 1: STORE_PREV_BATCH(1); break;
+          case 2: STORE_PREV_BATCH(2); break;
+          case 3: STORE_PREV_BATCH(3); break;
+          case 4: STORE_PREV_BATCH(4); break;
+          case 5: STORE_PREV_BATCH(5); break;
+          case 6: STORE_PREV_BATCH(6); break;
+          case 7: STORE_PREV_BATCH(7); break;
+          default: break;
+        }
       }
+      const unsigned char* sa = smem + buf * T_BUFBYTES;
+      const unsigned char* sb = sa + T_OPBYTES;
+      unsigned char* da = smem + (buf ^ 1) * T_BUFBYTES;
+      if (t + 1 < it.nk) {
+        stage_glds<TA>(it.A, p.lda, it.tm0, it.kbeg + (long long)(t + 1) * T_BK, da, tid);
+        stage_glds<TB>(it.B, p.ldb, it.tn0, it.kbeg + (long long)(t + 1) * T_BK, da + T_OPBYTES, tid);
+      } else if (have_next && !atomic) {  // cross-item prefetch (the atomic epilogue needs the LDS itself)
+        stage_glds<TA>(nx.A, p.lda, nx.tm0, nx.kbeg, da, tid);
+        stage_glds<TB>(nx.B, p.ldb, nx.tn0, nx.kbeg, da + T_OPBYTES, tid);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++) {
+        bf8v fa[4], fb[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          fa[i] = TA ? frag_kmajor(sa, wm * 64 + i * 16, ks, lane) : frag_rowmajor(sa, wm * 64 + i * 16, ks, lane);
+          fb[i] = TB ? frag_kmajor(sb, wn * 64 + i * 16, ks, lane) : frag_rowmajor(sb, wn * 64 + i * 16, ks, lane);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+          for (int j = 0; j < 4; j++)  // swapped operands: D[n][m], so a lane holds 4 consecutive n of one m
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+      }
+      buf ^= 1;
+    }
+    if (have_prev && it.nk < 8) {  // short main loop: flush the store blocks that found no k-step
+      if (it.nk <= 0) STORE_PREV_BATCH(0);
+      if (it.nk <= 1) STORE_PREV_BATCH(1);
+      if (it.nk <= 2) STORE_PREV_BATCH(2);
+      if (it.nk <= 3) STORE_PREV_BATCH(3);
+      if (it.nk <= 4) STORE_PREV_BATCH(4);
+      if (it.nk <= 5) STORE_PREV_BATCH(5);
+      if (it.nk <= 6) STORE_PREV_BATCH(6);
+      if (it.nk <= 7) STORE_PREV_BATCH(7);
+    }
+    have_prev = false;
+
+    if (atomic) {
+      // split-K partial tile: stage through LDS so that every atomic wave-instruction adds 256 contiguous bytes
+      lds_barrier();
 #pragma unroll
       for (int i = 0; i < 4; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++)  // swapped operands: D[n][m], so a lane holds 4 consecutive n of one m
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-    }
-  }
-  __syncthreads();  // all fragment reads done before the epilogue reuses the LDS
-
-  // ---- epilogue: accumulators -> LDS (f32) -> coalesced global rows ---------------------------------
-#pragma unroll
-  for (int i = 0; i < 4; i++)
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int m = wm * 64 + i * 16 + (lane & 15);
-      const int n = wn * 64 + j * 16 + (lane >> 4) * 4;
-      *(f4v*)(smem + m * T_EPI_PITCH + n * 4) = acc[i][j];
-    }
-  __syncthreads();
-
-  if (OUTF32 && (p.flags & PERO_GEMM_ATOMIC)) {
-    float* C = (float*)p.C + coff;
+        for (int j = 0; j < 4; j++)
+          *(f4v*)(smem + (lm + i * 16) * T_EPI_PITCH + (ln + j * 16) * 4) = acc[i][j];
+      lds_barrier();
+      float* C = (float*)p.C + it.coff;
 #pragma unroll 4
-    for (int i = 0; i < 32; i++) {
-      const int row = wave + 4 * i;
+      for (int i = 0; i < 32; i++) {
+        const int row = wave + 4 * i;
 #pragma unroll
-      for (int j = 0; j < 2; j++) {
-        const int col = lane + 64 * j;
-        const float v = *(const float*)(smem + row * T_EPI_PITCH + col * 4) * p.alpha;
-        atomicAdd(C + (tm0 + row) * p.ldc + tn0 + col, v);
+        for (int j = 0; j < 2; j++) {
+          const int col = lane + 64 * j;
+          const float v = *(const float*)(smem + row * T_EPI_PITCH + col * 4) * p.alpha;
+          atomicAdd(C + (it.tm0 + row) * p.ldc + it.tn0 + col, v);
+        }
       }
-    }
-    return;
-  }
-
-  const int c8 = (tid & 15) * 8;
-  float bias[8];
-#pragma unroll
-  for (int e = 0; e < 8; e++) bias[e] = p.bias ? p.bias[tn0 + c8 + e] : 0.f;
-#pragma unroll
-  for (int i = 0; i < 8; i++) {
-    const int row = (tid >> 4) + 16 * i;
-    const f4v v0 = *(const f4v*)(smem + row * T_EPI_PITCH + c8 * 4);
-    const f4v v1 = *(const f4v*)(smem + row * T_EPI_PITCH + c8 * 4 + 16);
-    float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-#pragma unroll
-    for (int e = 0; e < 8; e++) v[e] = v[e] * p.alpha + bias[e];
-    const long long grow = tm0 + row;
-    if (p.resid) {
-      const uint4 rr = *(const uint4*)((const bf16raw*)p.resid + coff + grow * p.ldr + tn0 + c8);
-      const unsigned w[4] = {rr.x, rr.y, rr.z, rr.w};
-#pragma unroll
-      for (int e = 0; e < 4; e++) {
-        v[2 * e] += __uint_as_float(w[e] << 16);
-        v[2 * e + 1] += __uint_as_float(w[e] & 0xffff0000u);
+      if (have_next) {
+        lds_barrier();  // staging reads done before the next item's DMA overwrites the LDS
+        stage_glds<TA>(nx.A, p.lda, nx.tm0, nx.kbeg, smem, tid);
+        stage_glds<TB>(nx.B, p.ldb, nx.tn0, nx.kbeg, smem + T_OPBYTES, tid);
+        buf = 0;
       }
-    }
-    if (p.flags & PERO_GEMM_RELU) {
-#pragma unroll
-      for (int e = 0; e < 8; e++) v[e] = fmaxf(v[e], 0.f);
-    }
-    if (p.gate) {
-      const uint4 gg = *(const uint4*)((const bf16raw*)p.gate + coff + grow * p.ldg + tn0 + c8);
-      const unsigned w[4] = {gg.x, gg.y, gg.z, gg.w};
-#pragma unroll
-      for (int e = 0; e < 4; e++) {
-        if (!(__uint_as_float(w[e] << 16) > 0.f)) v[2 * e] = 0.f;
-        if (!(__uint_as_float(w[e] & 0xffff0000u) > 0.f)) v[2 * e + 1] = 0.f;
-      }
-    }
-    if (OUTF32) {
-      float* C = (float*)p.C + coff + grow * p.ldc + tn0 + c8;
-      if (p.flags & PERO_GEMM_ACCUM) {
-        const f4v o0 = *(const f4v*)C, o1 = *(const f4v*)(C + 4);
-#pragma unroll
-        for (int e = 0; e < 4; e++) { v[e] += o0[e]; v[4 + e] += o1[e]; }
-      }
-      *(f4v*)C = (f4v){v[0], v[1], v[2], v[3]};
-      *(f4v*)(C + 4) = (f4v){v[4], v[5], v[6], v[7]};
     } else {
-      bf16raw* C = (bf16raw*)p.C + coff + grow * p.ldc + tn0 + c8;
-      uint4 o;
-      o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]); o.z = pack2bf(v[4], v[5]); o.w = pack2bf(v[6], v[7]);
-      *(uint4*)C = o;
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) prev[i][j] = acc[i][j];
+      pm = it.tm0 + lm; pn = it.tn0 + ln; pcoff = it.coff;
+      have_prev = true;
     }
+    if (!have_next) break;
+    w = wnext;
+    it = nx;
   }
+  if (have_prev) {
+#pragma unroll
+    for (int b = 0; b < 8; b++) { STORE_PREV_BATCH(b); }
+  }
+#undef STORE_PREV
+#undef STORE_PREV_BATCH
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -292,6 +355,17 @@ __global__ __launch_bounds__(256) void gemm_generic(GemmP p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// 0 = default: the simple one-tile-per-workgroup 128x128x64 kernel (gemm_o.hip) - fastest INSIDE the training step on every
+// interleaved same-process A/B (tools/step_ab.py: 17.97 ms vs 19.2 ms for the others at 128 lines); isolated, hot-cache
+// micro-benchmarks ranked the variants differently.  1 = persistent 128-tile (deferred epilogue), 2 = 256-tile,
+// 3 = 128x128x32 four-workgroups-per-CU, 6 = shape-based mix of 2 and 3 (+1 for split-K atomics).
+static int g_gemm_policy = 0;
+extern "C" int pero_set_option(const char* name, int value) {
+  if (name && !strcmp(name, "gemm_policy")) { g_gemm_policy = value; return PERO_OK; }
+  pero_set_error("pero_set_option: unknown option %s", name ? name : "(null)");
+  return PERO_E_INVALID;
+}
+
 extern "C" int pero_gemm(const void* A, const void* B, void* C, const float* bias, const void* residual, const void* gate,
                          int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int64_t ldg,
                          int64_t batch, int64_t batch_inner,
@@ -302,7 +376,7 @@ extern "C" int pero_gemm(const void* A, const void* B, void* C, const float* bia
                (long long)M, (long long)N, (long long)K, (long long)batch);
   PERO_REQUIRE((in_dtype == PERO_F32 || in_dtype == PERO_BF16) && (out_dtype == PERO_F32 || out_dtype == PERO_BF16), "pero_gemm: bad dtype");
   PERO_REQUIRE(!((flags & (PERO_GEMM_ATOMIC | PERO_GEMM_ACCUM)) && out_dtype != PERO_F32), "pero_gemm: ATOMIC/ACCUM need f32 C");
-  PERO_REQUIRE(k_split >= 1 && (k_split == 1 || (flags & PERO_GEMM_ATOMIC)), "pero_gemm: k_split > 1 needs PERO_GEMM_ATOMIC");
+  PERO_REQUIRE(k_split >= 0 && (k_split == 1 || (flags & PERO_GEMM_ATOMIC)), "pero_gemm: k_split != 1 needs PERO_GEMM_ATOMIC");
   PERO_REQUIRE(batch < 65536, "pero_gemm: batch too large");
   const bool ta = flags & PERO_GEMM_TRANS_A, tb = flags & PERO_GEMM_TRANS_B;
   GemmP p;
@@ -318,14 +392,65 @@ extern "C" int pero_gemm(const void* A, const void* B, void* C, const float* bia
               (sAo % 8 == 0) && (sAi % 8 == 0) && (sBo % 8 == 0) && (sBi % 8 == 0) && ((sCo * esz_o) % 16 == 0) &&
               ((sCi * esz_o) % 16 == 0) && (!residual || (ldr % 8 == 0 && aligned16(residual))) &&
               (!gate || (ldg % 8 == 0 && aligned16(gate))) && (!(residual || gate) || out_dtype == PERO_BF16 || true);
+  if (fast && !(flags & (PERO_GEMM_TILE128 | PERO_GEMM_TILE256 | PERO_GEMM_TILE_S))) {
+    if (g_gemm_policy == 1) flags |= PERO_GEMM_TILE128;
+    else if (g_gemm_policy == 2) flags |= PERO_GEMM_TILE256;
+    else if (g_gemm_policy == 3) flags |= PERO_GEMM_TILE_S;
+    p.flags = flags;
+  }
+  const bool forced0 = flags & (PERO_GEMM_TILE128 | PERO_GEMM_TILE256 | PERO_GEMM_TILE_S);
   if (fast) {
+    // tile-size / split-K policy.  256x256 tiles halve the L2->LDS bytes per flop; they need ~a CU-count of work
+    // items.  k_split == 0 (with PERO_GEMM_ATOMIC) lets the library choose the split.
+    const bool atomic = flags & PERO_GEMM_ATOMIC;
+    const bool can256 = M % 256 == 0 && N % 256 == 0 && !(flags & PERO_GEMM_TILE128);
+    const long long t256 = can256 ? (M / 256) * (N / 256) * batch : 0;
+    const long long t128 = (M / T_BM) * (N / T_BN) * batch;
+    // (measured on the step's shapes: with the deferred epilogue the 128-tile kernel is as fast or faster than the
+    //  256-tile one, whose epilogue is not deferred - it would need 256 accumulator VGPRs; 256 tiles stay opt-in)
+    bool use256 = false;
+    (void)t256;
+    if (atomic && k_split == 0) {
+      long long ks = (512 + t128 - 1) / t128;
+      if (ks > K / 512) ks = K / 512;
+      if (ks < 1) ks = 1;
+      k_split = (int)ks;
+    } else if (k_split < 1) {
+      k_split = 1;
+    }
+    if (g_gemm_policy == 0 && !forced0 && pero_launch_gemm_o128(p, batch, k_split, ta, tb, out_dtype == PERO_F32, st)) {
+      PERO_CHECK_LAUNCH("pero_gemm(bf16 o128)");
+      return PERO_OK;
+    }
+    if (flags & PERO_GEMM_TILE256) use256 = can256;
+    // default for non-atomic products (measured, M = 32768): the four-workgroups-per-CU 128x128x32 kernel wins on
+    // every shape of the step except long-K products with a small output (K >= 2048), where the 256 tile wins
+    const bool forced = flags & (PERO_GEMM_TILE128 | PERO_GEMM_TILE256 | PERO_GEMM_TILE_S);
+    if (!forced && !atomic) {
+      if (K >= 2048 && t256 >= 192 && !tb) use256 = true;
+    }
+    if (((flags & PERO_GEMM_TILE_S) || (!forced && !use256)) && !atomic &&
+        pero_launch_gemm_s128(p, batch, k_split, ta, tb, out_dtype == PERO_F32, st)) {
+      PERO_CHECK_LAUNCH("pero_gemm(bf16 s128)");
+      return PERO_OK;
+    }
+    if (use256 && pero_launch_gemm_t256(p, batch, k_split, ta, tb, out_dtype == PERO_F32, st)) {
+      PERO_CHECK_LAUNCH("pero_gemm(bf16 256-tile)");
+      return PERO_OK;
+    }
     if (k_split > 1) {
+
       long long steps = K / T_BK;
       long long per = (steps + k_split - 1) / k_split;
       p.kchunk = per * T_BK;
       k_split = (int)((steps + per - 1) / per);
     }
-    dim3 grid((unsigned)((M / T_BM) * (N / T_BN)), (unsigned)batch, (unsigned)k_split), block(256);
+    const long long nwork = (M / T_BM) * (N / T_BN) * batch * k_split;
+    static int num_cus = 0;
+    if (!num_cus) { hipDeviceProp_t prop; int dev = 0; hipGetDevice(&dev); hipGetDeviceProperties(&prop, dev); num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256; }
+    const long long resident = 2LL * num_cus;  // 2 workgroups per CU (LDS-limited)
+    dim3 grid((unsigned)(nwork < resident ? nwork : resident)), block(256);
+    const int nbatch = (int)batch;
 #define LAUNCH_FAST(TA_, TB_, OF_)                                                                                        \
   do {                                                                                                                    \
     static bool attr_set = false;                                                                                         \
@@ -333,7 +458,7 @@ extern "C" int pero_gemm(const void* A, const void* B, void* C, const float* bia
       hipFuncSetAttribute((const void*)gemm_bf16_t128<TA_, TB_, OF_>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES); \
       attr_set = true;                                                                                                    \
     }                                                                                                                     \
-    hipLaunchKernelGGL((gemm_bf16_t128<TA_, TB_, OF_>), grid, block, T_LDS_BYTES, st, p);                                 \
+    hipLaunchKernelGGL((gemm_bf16_t128<TA_, TB_, OF_>), grid, block, T_LDS_BYTES, st, p, nbatch, nwork);                                 \
   } while (0)
     const bool of = out_dtype == PERO_F32;
     if (!ta && !tb) { if (of) LAUNCH_FAST(false, false, true); else LAUNCH_FAST(false, false, false); }

@@ -1,0 +1,34 @@
+// Shared by the bf16 tile GEMM kernels (gemm.hip: 128x128 tiles, gemm256.hip: 256x256 tiles).
+#pragma once
+#include "common.hpp"
+
+struct GemmP {
+  const void* A; const void* B; void* C;
+  const float* bias; const void* resid; const void* gate;
+  long long M, N, K, lda, ldb, ldc, ldr, ldg;
+  long long sAo, sAi, sBo, sBi, sCo, sCi;
+  int binner; float alpha; int flags; long long kchunk;
+};
+
+
+// K-major LDS images: 32-byte blocks of a k-row are XORed with fk(krow) so that the two transposed 8-byte reads of
+// a fragment (k-rows 8g+q and 8g+q+4 of the 4 lane groups) hit 32 distinct 8-byte slots of the 256-byte bank row.
+__device__ __forceinline__ int fk(int krow) { return (krow & 3) | (((krow >> 3) & 1) << 2); }
+
+template <int N_>
+__device__ __forceinline__ void wait_vmcnt() {
+  if (N_ == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+}
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");  // keep later LDS accesses below the barrier
+}
+
+// host entry of the 256x256 kernel (gemm256.hip); returns false when the shape does not qualify
+bool pero_launch_gemm_t256(const GemmP& p, long long batch, int k_split, bool ta, bool tb, bool out_f32, hipStream_t st);
+// host entry of the occupancy-tuned 128x128x32 kernel (gemm_s.hip)
+bool pero_launch_gemm_s128(const GemmP& p, long long batch, int k_split, bool ta, bool tb, bool out_f32, hipStream_t st);
+// host entry of the simple one-tile-per-workgroup 128x128x64 kernel (gemm_o.hip)
+bool pero_launch_gemm_o128(const GemmP& p, long long batch, int k_split, bool ta, bool tb, bool out_f32, hipStream_t st);

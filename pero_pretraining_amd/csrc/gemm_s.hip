@@ -1,0 +1,180 @@
+// 128 x 128 x 32 bf16 tile GEMM tuned for OCCUPANCY (gfx950): 32 KiB of LDS and <= 128 VGPRs per workgroup, so four
+// workgroups (16 waves) share a CU.  Motivation (measured on the step's shapes): vmcnt counts stores in issue order, so
+// a wave that has issued its tile's stores cannot get past its next LDS-DMA wait until they reached HBM; neither
+// persistence + prefetch nor deferring the stores into the next main loop hid that (both measured slower or equal).
+// What hides it is other resident workgroups: while one drains its stores, three others run their main loops.
+// Same contract / operand images as gemm_bf16_t128, BK = 32 (one MFMA k-step per LDS tile), direct epilogue.
+#include "gemm_common.hpp"
+
+#define S_BM 128
+#define S_BN 128
+#define S_BK 32
+#define S_OPBYTES (128 * 32 * 2)     // 8 KiB per operand tile
+#define S_BUFBYTES (2 * S_OPBYTES)   // 16 KiB per stage
+#define S_LDS_BYTES (2 * S_BUFBYTES) // 32 KiB
+
+// K-contiguous image [128 rows][32 k] = 64-byte rows, 4 chunks of 16 B; chunk ^ ((row >> 2) & 3) makes the 16 rows
+// a ds_read_b128 lane group touches land on 16 distinct 16-byte slots of the 256-byte bank row.
+__device__ __forceinline__ bf8v sfrag_rowmajor(const unsigned char* base, int row, int lane) {
+  const int r = row + (lane & 15);
+  const int chunk = lane >> 4;
+  return *(const bf8v*)(base + r * 64 + ((chunk ^ ((r >> 2) & 3)) << 4));
+}
+// K-major image [32 k-rows][128 cols] = 256-byte rows (as gemm.hip, one k-step)
+__device__ __forceinline__ bf8v sfrag_kmajor(const unsigned char* base, int col, int lane) {
+  const int i = lane & 15;
+  const int krow = 8 * (lane >> 4) + (i >> 2);
+  const unsigned char* a = base + krow * 256 + ((((col >> 4) ^ fk(krow))) << 5) + 8 * (i & 3);
+  s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s4v, a));
+  s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s4v, a + 4 * 256));
+  typedef short s8v __attribute__((ext_vector_type(8)));
+  s8v v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf8v, v);
+}
+// 8 KiB operand tile = 8 pieces of 1 KiB; wave w issues pieces w and w + 4
+template <bool TR>
+__device__ __forceinline__ void sstage_glds(const bf16raw* X, long long ld, long long tile0, long long k0,
+                                            unsigned char* lds_base, int tid) {
+  const bf16raw* p;
+  long long step;
+  if (!TR) {  // piece = 16 rows x 64 B: thread -> row (tid >> 2) + 64 i, LDS slot tid & 3
+    const int row = tid >> 2, chunk = (tid & 3) ^ ((row >> 2) & 3);
+    p = X + (tile0 + row) * ld + k0 + chunk * 8;
+    step = 64 * ld;
+  } else {    // piece = 4 k-rows x 256 B: thread -> k-row (tid >> 4) + 16 i, LDS slot tid & 15
+    const int krow = tid >> 4, slot = tid & 15;
+    const int chunk = ((((slot >> 1) ^ fk(krow))) << 1) | (slot & 1);
+    p = X + (k0 + krow) * ld + tile0 + chunk * 8;
+    step = 16 * ld;
+  }
+  unsigned char* dst = lds_base + (tid >> 6) * 1024;
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p), (__attribute__((address_space(3))) void*)(dst), 16, 0, 0);
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p + step), (__attribute__((address_space(3))) void*)(dst + 4096), 16, 0, 0);
+}
+
+template <bool TA, bool TB, bool OUTF32>
+__global__ __launch_bounds__(256, 4) void gemm_bf16_s128(GemmP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ntn = (int)(p.N / S_BN);
+  const int nt = (int)(p.M / S_BM) * ntn;
+  const int bid = blockIdx.x;
+  const int q = nt >> 3, r8 = nt & 7, xcd = bid & 7, loc = bid >> 3;
+  const int id = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + loc;
+  const long long tm0 = (long long)(id / ntn) * S_BM, tn0 = (long long)(id % ntn) * S_BN;
+  const int b = blockIdx.y;
+  const long long bo = b / p.binner, bi = b % p.binner;
+  const bf16raw* A = (const bf16raw*)p.A + bo * p.sAo + bi * p.sAi;
+  const bf16raw* B = (const bf16raw*)p.B + bo * p.sBo + bi * p.sBi;
+  const long long coff = bo * p.sCo + bi * p.sCi;
+  const long long kbeg = (long long)blockIdx.z * p.kchunk;
+  long long kend = kbeg + p.kchunk;
+  if (kend > p.K) kend = p.K;
+  const int nk = (int)((kend - kbeg) / S_BK);
+
+  f4v acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = (f4v){0.f, 0.f, 0.f, 0.f};
+
+  if (nk > 0) {
+    sstage_glds<TA>(A, p.lda, tm0, kbeg, smem, tid);
+    sstage_glds<TB>(B, p.ldb, tn0, kbeg, smem + S_OPBYTES, tid);
+  }
+  for (int t = 0; t < nk; t++) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const unsigned char* sa = smem + (t & 1) * S_BUFBYTES;
+    const unsigned char* sb = sa + S_OPBYTES;
+    if (t + 1 < nk) {
+      unsigned char* da = smem + ((t + 1) & 1) * S_BUFBYTES;
+      sstage_glds<TA>(A, p.lda, tm0, kbeg + (long long)(t + 1) * S_BK, da, tid);
+      sstage_glds<TB>(B, p.ldb, tn0, kbeg + (long long)(t + 1) * S_BK, da + S_OPBYTES, tid);
+    }
+    bf8v fa[4], fb[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      fa[i] = TA ? sfrag_kmajor(sa, wm * 64 + i * 16, lane) : sfrag_rowmajor(sa, wm * 64 + i * 16, lane);
+      fb[i] = TB ? sfrag_kmajor(sb, wn * 64 + i * 16, lane) : sfrag_rowmajor(sb, wn * 64 + i * 16, lane);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+  }
+
+  const bool atomic = OUTF32 && (p.flags & PERO_GEMM_ATOMIC);
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const long long n = tn0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+    f4v bias = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) bias = *(const f4v*)(p.bias + n);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const long long m = tm0 + wm * 64 + i * 16 + (lane & 15);
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) v[e] = acc[i][j][e] * p.alpha + bias[e];
+      if (OUTF32 && atomic) {
+        float* C = (float*)p.C + coff + m * p.ldc + n;
+#pragma unroll
+        for (int e = 0; e < 4; e++) atomicAdd(C + e, v[e]);
+        continue;
+      }
+      if (p.resid) {
+        const uint2 rr = *(const uint2*)((const bf16raw*)p.resid + coff + m * p.ldr + n);
+        v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
+        v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
+      }
+      if (p.flags & PERO_GEMM_RELU) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.f);
+      }
+      if (p.gate) {
+        const uint2 gg = *(const uint2*)((const bf16raw*)p.gate + coff + m * p.ldg + n);
+        if (!(__uint_as_float(gg.x << 16) > 0.f)) v[0] = 0.f;
+        if (!(__uint_as_float(gg.x & 0xffff0000u) > 0.f)) v[1] = 0.f;
+        if (!(__uint_as_float(gg.y << 16) > 0.f)) v[2] = 0.f;
+        if (!(__uint_as_float(gg.y & 0xffff0000u) > 0.f)) v[3] = 0.f;
+      }
+      if (OUTF32) {
+        float* C = (float*)p.C + coff + m * p.ldc + n;
+        if (p.flags & PERO_GEMM_ACCUM) {
+          const f4v o = *(const f4v*)C;
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] += o[e];
+        }
+        *(f4v*)C = (f4v){v[0], v[1], v[2], v[3]};
+      } else {
+        uint2 o;
+        o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
+        *(uint2*)((bf16raw*)p.C + coff + m * p.ldc + n) = o;
+      }
+    }
+  }
+}
+
+bool pero_launch_gemm_s128(const GemmP& p0, long long batch, int k_split, bool ta, bool tb, bool out_f32, hipStream_t st) {
+  if (p0.M % S_BM || p0.N % S_BN || p0.K % S_BK) return false;
+  GemmP p = p0;
+  if (k_split > 1) {
+    const long long steps = p.K / S_BK;
+    const long long per = (steps + k_split - 1) / k_split;
+    p.kchunk = per * S_BK;
+    k_split = (int)((steps + per - 1) / per);
+  } else {
+    p.kchunk = p.K;
+    k_split = 1;
+  }
+  dim3 grid((unsigned)((p.M / S_BM) * (p.N / S_BN)), (unsigned)batch, (unsigned)k_split), block(256);
+#define LAUNCH_S(TA_, TB_, OF_) hipLaunchKernelGGL((gemm_bf16_s128<TA_, TB_, OF_>), grid, block, S_LDS_BYTES, st, p)
+  if (!ta && !tb) { if (out_f32) LAUNCH_S(false, false, true); else LAUNCH_S(false, false, false); }
+  else if (!ta && tb) { if (out_f32) LAUNCH_S(false, true, true); else LAUNCH_S(false, true, false); }
+  else if (ta && tb) { if (out_f32) LAUNCH_S(true, true, true); else LAUNCH_S(true, true, false); }
+  else { if (out_f32) LAUNCH_S(true, false, true); else LAUNCH_S(true, false, false); }
+#undef LAUNCH_S
+  return true;
+}

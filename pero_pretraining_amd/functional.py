@@ -42,8 +42,7 @@ def linear_bwd(dy, x, w, b, dtype, need_dx=True, gate=None, residual=None, bias_
     """dy (M,N), x (M,K), w (N,K).  Accumulates dW (+db) into .grad; returns dx = dy @ W (+residual)(*gate>0)."""
     if w.requires_grad:
         gw = ensure_grad(w)
-        ops.gemm(dy, x, out=gw.view(w.shape[0], -1), trans_a=True, trans_b=True, atomic=True,
-                 k_split=_ksplit(dy.shape[0], w.numel()))
+        ops.gemm(dy, x, out=gw.view(w.shape[0], -1), trans_a=True, trans_b=True, atomic=True, k_split=0)
     if b is not None and b.requires_grad and not bias_grad_done:
         ops.colsum(dy, ensure_grad(b))
     if not need_dx:
@@ -90,10 +89,16 @@ def attention_bwd(qkv, p, dout, n, s, h):
 # ---------------------------------------------------------------------------------------------
 # one post-norm encoder layer (torch.nn.TransformerEncoderLayer semantics, models/transformers.py:36-43)
 # ---------------------------------------------------------------------------------------------
+FUSED_ATTENTION = True  # bf16, head_dim 128, S % 128 == 0: flash-style HIP kernels; else batched GEMM + softmax
+
+
 def layer_fwd(t, L, n, s, h, dtype, save):
     at = L.self_attn
     qkv = linear_fwd(t, at.in_proj_weight, at.in_proj_bias, dtype)
-    a, p = attention_fwd(qkv, n, s, h)
+    if FUSED_ATTENTION and ops.attention_fused_ok(qkv, s, h):
+        a, p = ops.attention_fwd_fused(qkv, n, s, h)   # p = base-2 log-sum-exp rows (N*h, S)
+    else:
+        a, p = attention_fwd(qkv, n, s, h)             # p = probabilities (N*h, S, S)
     y1 = linear_fwd(a, at.out_proj.weight, at.out_proj.bias, dtype, residual=t)
     t1, mean1, rstd1 = ops.layernorm_fwd(y1, L.norm1.weight.detach(), L.norm1.bias.detach(), L.norm1.eps)
     hdn = linear_fwd(t1, L.linear1.weight, L.linear1.bias, dtype, relu=True)
@@ -114,7 +119,10 @@ def layer_bwd(dt2, L, saved, n, s, h, dtype):
     dy1 = ops.layernorm_bwd(dt1, y1, mean1, rstd1, L.norm1.weight.detach(), ensure_grad(L.norm1.weight),
                             ensure_grad(L.norm1.bias), ensure_grad(at.out_proj.bias))
     da = linear_bwd(dy1, a, at.out_proj.weight, at.out_proj.bias, dtype, bias_grad_done=True)
-    dqkv = attention_bwd(qkv, p, da, n, s, h)
+    if p.dim() == 2:
+        dqkv = ops.attention_bwd_fused(qkv, a, da, p, n, s, h)
+    else:
+        dqkv = attention_bwd(qkv, p, da, n, s, h)
     return linear_bwd(dqkv, t, at.in_proj_weight, at.in_proj_bias, dtype, residual=dy1)
 
 
@@ -172,7 +180,7 @@ def backbone_bwd(mod, saved, dt, dtype, on_layer_done=None):
         linear_bwd(dy0, a0, cw, mod.conv_layer.bias, dtype, need_dx=False, bias_grad_done=True)
     elif cw.requires_grad:  # padded pitch: dW into a (d, pitch) scratch, then add the real columns into .grad
         tmp = torch.zeros((cw.shape[0], a0.shape[1]), device=a0.device, dtype=torch.float32)
-        ops.gemm(dy0, a0, out=tmp, trans_a=True, trans_b=True, atomic=True, k_split=_ksplit(dy0.shape[0], tmp.numel()))
+        ops.gemm(dy0, a0, out=tmp, trans_a=True, trans_b=True, atomic=True, k_split=0)
         ops.add_rows2d(ensure_grad(cw).view(cw.shape[0], kp), tmp, kp)
     if on_layer_done is not None:
         on_layer_done(-1)

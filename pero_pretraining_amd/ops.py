@@ -51,11 +51,11 @@ def gemm_raw(A, B, C, M, N, K, lda, ldb, ldc, *, bias=None, residual=None, gate=
         e1.record()
         fast = idt == PERO_BF16 and M % 128 == 0 and N % 128 == 0 and K % 64 == 0 and not (flags & GEMM_FORCE_GENERIC)
         lay = ("T" if flags & GEMM_TRANS_A else "N") + ("T" if flags & GEMM_TRANS_B else "N")
-        gemm_timeline.append((e0, e1, 2.0 * M * N * K * batch, ("gemm_bf16_t128" if fast else "gemm_generic") + ":" + lay))
+        gemm_timeline.append((e0, e1, 2.0 * M * N * K * batch, ("gemm_bf16_tile" if fast else "gemm_generic") + ":" + lay))
 
 
 def gemm(a, b, out=None, *, bias=None, residual=None, gate=None, trans_a=False, trans_b=False, relu=False,
-         alpha=1.0, out_dtype=None, atomic=False, accum=False, k_split=1, force_generic=False):
+         alpha=1.0, out_dtype=None, atomic=False, accum=False, k_split=1, force_generic=False, extra_flags=0):
     """out[M,N] = alpha * op(a) @ op(b)^T ...   a: [M,K] ([K,M] if trans_a); b: [N,K] ([K,N] if trans_b).
     Row-strided 2-D views are fine (unit stride in the last dim)."""
     assert a.dim() == 2 and b.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1
@@ -66,7 +66,7 @@ def gemm(a, b, out=None, *, bias=None, residual=None, gate=None, trans_a=False, 
         out = torch.empty((M, N), device=a.device, dtype=out_dtype or a.dtype)
     assert out.shape == (M, N) and out.stride(1) == 1
     flags = (GEMM_RELU if relu else 0) | (GEMM_TRANS_A if trans_a else 0) | (GEMM_TRANS_B if trans_b else 0) | \
-        (GEMM_ATOMIC if atomic else 0) | (GEMM_ACCUM if accum else 0) | (GEMM_FORCE_GENERIC if force_generic else 0)
+        (GEMM_ATOMIC if atomic else 0) | (GEMM_ACCUM if accum else 0) | (GEMM_FORCE_GENERIC if force_generic else 0) | extra_flags
     gemm_raw(a, b, out, M, N, K, a.stride(0), b.stride(0), out.stride(0), bias=bias, residual=residual, gate=gate,
              ldr=residual.stride(0) if residual is not None else 0, ldg=gate.stride(0) if gate is not None else 0,
              alpha=alpha, flags=flags, k_split=k_split)
@@ -105,6 +105,27 @@ def softmax_bwd(p, dp, scale):
     ds = torch.empty_like(p)
     call("pero_softmax_bwd", ptr(p), ptr(dp), ptr(ds), rows, cols, float(scale), dt(p), stream())
     return ds
+
+
+def attention_fused_ok(qkv, s, h):
+    d = qkv.shape[1] // 3
+    return qkv.dtype == torch.bfloat16 and d // h == 128 and d % h == 0 and s % 128 == 0
+
+
+def attention_fwd_fused(qkv, n, s, h):
+    d = qkv.shape[1] // 3
+    out = torch.empty((n * s, d), device=qkv.device, dtype=qkv.dtype)
+    lse = torch.empty((n * h, s), device=qkv.device, dtype=torch.float32)
+    call("pero_attention_fwd", ptr(qkv), ptr(out), ptr(lse), n, s, h, d // h, dt(qkv), stream())
+    return out, lse
+
+
+def attention_bwd_fused(qkv, out, dout, lse, n, s, h):
+    d = qkv.shape[1] // 3
+    dqkv = torch.empty_like(qkv)
+    dvec = torch.empty((n * h, s), device=qkv.device, dtype=torch.float32)
+    call("pero_attention_bwd", ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(dvec), ptr(dqkv), n, s, h, d // h, dt(qkv), stream())
+    return dqkv
 
 
 def masked_ce_fwd(logits, labels, mask, unmasked_weight=None):

@@ -27,7 +27,7 @@ def test_library_exports_every_header_symbol():
     assert len(names) >= 20
     for n in names:
         assert hasattr(h, n), f"{n} declared in include/pero_hip.h but not exported"
-    assert set(_lib.SIGNATURES) | {"pero_last_error", "pero_abi_version"} == set(names)
+    assert set(_lib.SIGNATURES) | {"pero_last_error", "pero_abi_version", "pero_set_option"} == set(names)
     assert h.pero_abi_version() == 1
 
 

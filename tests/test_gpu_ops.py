@@ -102,6 +102,75 @@ def test_gemm_bf16_fast_epilogues_and_splitk(ops):
     assert rel_err(c, 2 * acc) < 1e-5
 
 
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
+def test_gemm_bf16_tile256_layouts_exact_integers(ops, ta, tb, out_dtype):
+    """256x256-tile kernel, forced: all operand layouts, several tiles per persistent workgroup, exact integers."""
+    from pero_pretraining_amd._lib import GEMM_TILE256
+    M, N, K = 512, 768, 320
+    g = torch.Generator().manual_seed(11)
+    a = torch.randint(-3, 4, (K, M) if ta else (M, K), generator=g).float()
+    b = torch.randint(-3, 4, (K, N) if tb else (N, K), generator=g).float()
+    ref = (a.t() if ta else a) @ (b.t() if tb else b).t()
+    out = ops.gemm(dev(a, torch.bfloat16), dev(b, torch.bfloat16), trans_a=ta, trans_b=tb, out_dtype=out_dtype,
+                   extra_flags=GEMM_TILE256)
+    assert torch.equal(out.float().cpu(), ref.to(out_dtype).float())
+
+
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
+def test_gemm_bf16_s128_layouts_and_epilogues(ops, ta, tb):
+    """128x128x32 high-occupancy kernel, forced: exact integers in all layouts + the fused epilogue."""
+    M, N, K = 384, 256, 160
+    g = torch.Generator().manual_seed(13)
+    a = torch.randint(-3, 4, (K, M) if ta else (M, K), generator=g).float()
+    b = torch.randint(-3, 4, (K, N) if tb else (N, K), generator=g).float()
+    ref = (a.t() if ta else a) @ (b.t() if tb else b).t()
+    for od in (torch.bfloat16, torch.float32):
+        out = ops.gemm(dev(a, torch.bfloat16), dev(b, torch.bfloat16), trans_a=ta, trans_b=tb, out_dtype=od, extra_flags=256)
+        assert torch.equal(out.float().cpu(), ref.to(od).float())
+    bias = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g).bfloat16()
+    gate = torch.randn(M, N, generator=g).bfloat16()
+    full = torch.relu(0.5 * ref.double() + bias.double() + res.double()) * (gate.double() > 0)
+    out = ops.gemm(dev(a, torch.bfloat16), dev(b, torch.bfloat16), trans_a=ta, trans_b=tb, bias=dev(bias), residual=dev(res),
+                   gate=dev(gate), relu=True, alpha=0.5, extra_flags=256)
+    assert rel_err(out, full) < 2 ** -8
+
+
+def test_gemm_bf16_tile256_epilogues_splitk_and_persistence(ops):
+    from pero_pretraining_amd._lib import GEMM_TILE256
+    M, N, K = 256 * 70, 512, 256   # 140 tiles... still < CUs; plus a > CU-count case below
+    g = torch.Generator().manual_seed(12)
+    a = torch.randn(M, K, generator=g).bfloat16()
+    b = torch.randn(N, K, generator=g).bfloat16()
+    bias = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g).bfloat16()
+    gate = torch.randn(M, N, generator=g).bfloat16()
+    acc = a.double() @ b.double().t()
+    ref = torch.relu(0.25 * acc + bias.double() + res.double()) * (gate.double() > 0)
+    out = ops.gemm(dev(a), dev(b), bias=dev(bias), residual=dev(res), gate=dev(gate), relu=True, alpha=0.25,
+                   extra_flags=GEMM_TILE256)
+    assert rel_err(out, ref) < 2 ** -8
+    # more work items than workgroups (persistent loop + cross-item prefetch): 1200 tiles
+    M2 = 256 * 300
+    a2 = torch.randn(M2, 64, generator=g).bfloat16()
+    b2 = torch.randn(1024, 64, generator=g).bfloat16()
+    out2 = ops.gemm(dev(a2), dev(b2), extra_flags=GEMM_TILE256)
+    assert rel_err(out2, a2.double() @ b2.double().t()) < 2 ** -8
+    out3 = ops.gemm(dev(a2), dev(b2))  # default policy picks a kernel itself
+    assert torch.equal(out2, out3) or rel_err(out3, out2.float()) < 2 ** -8
+    # split-K atomics on the 256 tile (weight-gradient form) incl. automatic split
+    at, bt = a.t().contiguous(), b.t().contiguous()  # (K=256, M) , (K, N): treat as [Kred][Mout]
+    x = torch.randn(4096, 512, generator=g).bfloat16()
+    dy = torch.randn(4096, 768, generator=g).bfloat16()
+    refw = dy.double().t() @ x.double()
+    c = torch.zeros(768, 512, device="cuda")
+    ops.gemm(dev(dy), dev(x), out=c, trans_a=True, trans_b=True, atomic=True, k_split=4, extra_flags=GEMM_TILE256)
+    assert rel_err(c, refw) < 1e-5
+    ops.gemm(dev(dy), dev(x), out=c, trans_a=True, trans_b=True, atomic=True, k_split=0)
+    assert rel_err(c, 2 * refw) < 1e-5
+
+
 def test_gemm_batched_strided_attention_shapes(ops):
     """Q K^T and P V as batched GEMMs straight out of the packed qkv tensor (two-level batch strides)."""
     n, s, h, hd = 2, 256, 2, 128
@@ -122,6 +191,36 @@ def test_gemm_batched_strided_attention_shapes(ops):
                  sA=(h * s * s, s * s), sB=(s * 3 * d, hd), sC=(s * d, hd), flags=GEMM_TRANS_B)
     ref_o = (p.double().reshape(n, h, s, s) @ v).permute(0, 2, 1, 3).reshape(n * s, d)
     assert rel_err(out, ref_o) < 2 ** -8
+
+
+@pytest.mark.parametrize("n,s,h", [(2, 256, 2), (1, 128, 4), (2, 384, 1)])
+def test_fused_attention_fwd_bwd(ops, n, s, h):
+    """Flash-style kernels (scores never stored) vs the oracle's attention on the same bf16 inputs (f64), and
+    the gradients through it; exercises 1, 2 and 3 key tiles (online softmax rescale)."""
+    hd = 128
+    d = h * hd
+    g = torch.Generator().manual_seed(n * 1000 + s + h)
+    qkv = (torch.randn(n * s, 3 * d, generator=g) * 0.7).bfloat16()
+    qkv[5, :d] *= 6.0          # a spiked query row: forces a large running-max jump between key tiles
+    qkv[s // 2 + 3, d:2 * d] *= 6.0
+    dout = torch.randn(n * s, d, generator=g).bfloat16()
+    ref_in = qkv.double().requires_grad_(True)
+    ref = O.attention(ref_in, n, s, h)
+    ref.backward(dout.double())
+    out, lse = ops.attention_fwd_fused(dev(qkv), n, s, h)
+    assert rel_err(out, ref.detach()) < 2 ** -7
+    # base-2 LSE of the scaled scores
+    q, k, _ = qkv.double().reshape(n, s, 3, h, hd).permute(2, 0, 3, 1, 4)
+    sc = (q @ k.transpose(-1, -2)) / math.sqrt(hd)
+    lse_ref = torch.logsumexp(sc, -1) / math.log(2.0)
+    assert float((lse.cpu().double().reshape(n, h, s) - lse_ref).abs().max()) < 2e-3
+    dqkv = ops.attention_bwd_fused(dev(qkv), out, dev(dout), lse, n, s, h)
+    gref = ref_in.grad
+    for name, sl in (("dq", slice(0, d)), ("dk", slice(d, 2 * d)), ("dv", slice(2 * d, 3 * d))):
+        err = rel_err(dqkv[:, sl], gref[:, sl])
+        assert err < 3e-2, (name, err)
+        a, b = dqkv[:, sl].double().cpu().flatten(), gref[:, sl].flatten()
+        assert float(a @ b / (a.norm() * b.norm())) > 0.9995, name
 
 
 # ------------------------------------------------------------------------------------------ row kernels

@@ -38,7 +38,7 @@ for (N, K, tag) in [(1536, 512, "qkv"), (512, 512, "out"), (2048, 512, "ffn1"), 
     dx = torch.empty(M, K, device=dev, dtype=torch.bfloat16)
     dw = torch.zeros(N, K, device=dev, dtype=torch.float32)
     fl = 2.0 * M * N * K
-    bench(f"{tag} NT y=x W^T  [{M}x{N}x{K}]", lambda: ops.gemm(x, w, out=y), fl)
-    bench(f"{tag} NN dx=dy W  [{M}x{K}x{N}]", lambda: ops.gemm(dy, w, out=dx, trans_b=True), fl)
-    for ks in (1, 2, 4, 8, 16):
-        bench(f"{tag} TT dW=dy^T x ksplit={ks}", lambda: ops.gemm(dy, x, out=dw, trans_a=True, trans_b=True, atomic=True, k_split=ks), fl)
+    for tname, tf in (("t128", 64), ("t256", 128), ("s128", 256)):
+        bench(f"{tag} NT y=x W^T  [{M}x{N}x{K}] {tname}", lambda: ops.gemm(x, w, out=y, extra_flags=tf), fl)
+        bench(f"{tag} NN dx=dy W  [{M}x{K}x{N}] {tname}", lambda: ops.gemm(dy, w, out=dx, trans_b=True, extra_flags=tf), fl)
+    bench(f"{tag} TT dW auto", lambda: ops.gemm(dy, x, out=dw, trans_a=True, trans_b=True, atomic=True, k_split=0), fl)

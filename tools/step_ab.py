@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Same-process A/B of library options on the full training step (devices differ by up to ~12 % between gpurun
+calls, so variants must be interleaved in ONE process).  usage: python tools/step_ab.py [batch] [rounds]"""
+import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+from pero_pretraining_amd import _lib
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+dev = torch.device("cuda", 0)
+model, opt, sched, trainer = bench.build(dev, True)
+batches = bench.synthetic(0, B, dev)
+
+def run(n):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for i in range(n):
+        sched.update_learning_rate(i); trainer.train_step_prepared(*batches[i % 2])
+    torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
+
+run(3)
+names = {0: "default (o128 simple)", 1: "t128 persistent", 2: "t256", 3: "s128 (4 WG/CU)", 6: "shape mix"}
+res = {k: [] for k in names}
+for r in range(rounds):
+    for pol in names:
+        _lib.lib().pero_set_option(b"gemm_policy", pol)
+        run(1)
+        res[pol].append(run(4))
+for pol, name in names.items():
+    v = sorted(res[pol])
+    print(f"policy {pol} {name:18s}: ms/step min {v[0]:.3f} median {v[len(v)//2]:.3f}  -> {B / v[len(v)//2] * 1e3:.0f} lines/s")
