@@ -355,10 +355,13 @@ __global__ __launch_bounds__(256) void gemm_generic(GemmP p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// 0 = default: the simple one-tile-per-workgroup 128x128x64 kernel (gemm_o.hip) - fastest INSIDE the training step on every
-// interleaved same-process A/B (tools/step_ab.py: 17.97 ms vs 19.2 ms for the others at 128 lines); isolated, hot-cache
-// micro-benchmarks ranked the variants differently.  1 = persistent 128-tile (deferred epilogue), 2 = 256-tile,
-// 3 = 128x128x32 four-workgroups-per-CU, 6 = shape-based mix of 2 and 3 (+1 for split-K atomics).
+// Tile-kernel policy, chosen by interleaved same-process A/B of the WHOLE training step (tools/step_ab.py; isolated
+// hot-cache micro-benchmarks ranked the variants differently, and devices differ by ~10 % between runs):
+//   0 = default: products with a stored output -> gemm_bf16_s128 (128x128x32, four workgroups per CU, LDS-staged
+//       coalesced epilogue); split-K atomic products (weight gradients) -> gemm_bf16_o128 (128x128x64, one tile per
+//       workgroup).  17.3 ms / step at 128 lines vs 17.9 (all o128), 19.2-21.9 (persistent / 256-tile variants).
+//   1 = persistent 128-tile with deferred epilogue, 2 = 256-tile, 3 = s128 + persistent for atomics, 4 = all o128,
+//   6 = shape-based mix of 2 and 3.
 static int g_gemm_policy = 0;
 extern "C" int pero_set_option(const char* name, int value) {
   if (name && !strcmp(name, "gemm_policy")) { g_gemm_policy = value; return PERO_OK; }
@@ -418,7 +421,8 @@ extern "C" int pero_gemm(const void* A, const void* B, void* C, const float* bia
     } else if (k_split < 1) {
       k_split = 1;
     }
-    if (g_gemm_policy == 0 && !forced0 && pero_launch_gemm_o128(p, batch, k_split, ta, tb, out_dtype == PERO_F32, st)) {
+    if (!forced0 && (g_gemm_policy == 4 || (g_gemm_policy == 0 && atomic)) &&
+        pero_launch_gemm_o128(p, batch, k_split, ta, tb, out_dtype == PERO_F32, st)) {
       PERO_CHECK_LAUNCH("pero_gemm(bf16 o128)");
       return PERO_OK;
     }
@@ -429,6 +433,7 @@ extern "C" int pero_gemm(const void* A, const void* B, void* C, const float* bia
     if (!forced && !atomic) {
       if (K >= 2048 && t256 >= 192 && !tb) use256 = true;
     }
+    if (g_gemm_policy == 0) use256 = (flags & PERO_GEMM_TILE256) && can256;
     if (((flags & PERO_GEMM_TILE_S) || (!forced && !use256)) && !atomic &&
         pero_launch_gemm_s128(p, batch, k_split, ta, tb, out_dtype == PERO_F32, st)) {
       PERO_CHECK_LAUNCH("pero_gemm(bf16 s128)");

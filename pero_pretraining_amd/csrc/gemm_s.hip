@@ -3,7 +3,8 @@
 // a wave that has issued its tile's stores cannot get past its next LDS-DMA wait until they reached HBM; neither
 // persistence + prefetch nor deferring the stores into the next main loop hid that (both measured slower or equal).
 // What hides it is other resident workgroups: while one drains its stores, three others run their main loops.
-// Same contract / operand images as gemm_bf16_t128, BK = 32 (one MFMA k-step per LDS tile), direct epilogue.
+// Same contract / operand images as gemm_bf16_t128, BK = 32 (one MFMA k-step per LDS tile), epilogue staged
+// through LDS in two 64-row halves.
 #include "gemm_common.hpp"
 
 #define S_BM 128
@@ -11,7 +12,8 @@
 #define S_BK 32
 #define S_OPBYTES (128 * 32 * 2)     // 8 KiB per operand tile
 #define S_BUFBYTES (2 * S_OPBYTES)   // 16 KiB per stage
-#define S_LDS_BYTES (2 * S_BUFBYTES) // 32 KiB
+#define S_EPI_PITCH 528                // f32 staging pitch (128 * 4 + 16)
+#define S_LDS_BYTES (64 * S_EPI_PITCH) // 33792 B >= 2 * S_BUFBYTES (32 KiB): four workgroups per CU
 
 // K-contiguous image [128 rows][32 k] = 64-byte rows, 4 chunks of 16 B; chunk ^ ((row >> 2) & 3) makes the 16 rows
 // a ds_read_b128 lane group touches land on 16 distinct 16-byte slots of the 256-byte bank row.
@@ -106,52 +108,70 @@ __global__ __launch_bounds__(256, 4) void gemm_bf16_s128(GemmP p) {
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
   }
 
-  const bool atomic = OUTF32 && (p.flags & PERO_GEMM_ATOMIC);
+  // ---- epilogue: f32 accumulators -> LDS in two 64-row halves -> whole 256-byte row segments to HBM (16-byte lanes).
+  // In-step A/B showed that full-line coalesced stores (and 16-byte residual / gate loads) matter more than the
+  // direct 8-byte-per-lane epilogue's lower instruction count.
+  const int c8 = (tid & 15) * 8;
+  float bias[8];
 #pragma unroll
-  for (int j = 0; j < 4; j++) {
-    const long long n = tn0 + wn * 64 + j * 16 + (lane >> 4) * 4;
-    f4v bias = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias) bias = *(const f4v*)(p.bias + n);
+  for (int e = 0; e < 8; e++) bias[e] = p.bias ? p.bias[tn0 + c8 + e] : 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const long long m = tm0 + wm * 64 + i * 16 + (lane & 15);
-      float v[4];
+  for (int half = 0; half < 2; half++) {
+    __syncthreads();  // main-loop reads (half 0) / previous half's staging reads (half 1) are done
+    if (wm == half) {
 #pragma unroll
-      for (int e = 0; e < 4; e++) v[e] = acc[i][j][e] * p.alpha + bias[e];
-      if (OUTF32 && atomic) {
-        float* C = (float*)p.C + coff + m * p.ldc + n;
+      for (int i = 0; i < 4; i++)
 #pragma unroll
-        for (int e = 0; e < 4; e++) atomicAdd(C + e, v[e]);
-        continue;
-      }
+        for (int j = 0; j < 4; j++)
+          *(f4v*)(smem + (i * 16 + (lane & 15)) * S_EPI_PITCH + (wn * 64 + j * 16 + (lane >> 4) * 4) * 4) = acc[i][j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++) {
+      const int row = (tid >> 4) + 16 * rr;
+      const f4v v0 = *(const f4v*)(smem + row * S_EPI_PITCH + c8 * 4);
+      const f4v v1 = *(const f4v*)(smem + row * S_EPI_PITCH + c8 * 4 + 16);
+      float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+      for (int e = 0; e < 8; e++) v[e] = v[e] * p.alpha + bias[e];
+      const long long grow = tm0 + half * 64 + row;
       if (p.resid) {
-        const uint2 rr = *(const uint2*)((const bf16raw*)p.resid + coff + m * p.ldr + n);
-        v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
-        v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
+        const uint4 rr4 = *(const uint4*)((const bf16raw*)p.resid + coff + grow * p.ldr + tn0 + c8);
+        const unsigned w[4] = {rr4.x, rr4.y, rr4.z, rr4.w};
+#pragma unroll
+        for (int e = 0; e < 4; e++) { v[2 * e] += __uint_as_float(w[e] << 16); v[2 * e + 1] += __uint_as_float(w[e] & 0xffff0000u); }
       }
       if (p.flags & PERO_GEMM_RELU) {
 #pragma unroll
-        for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.f);
+        for (int e = 0; e < 8; e++) v[e] = fmaxf(v[e], 0.f);
       }
       if (p.gate) {
-        const uint2 gg = *(const uint2*)((const bf16raw*)p.gate + coff + m * p.ldg + n);
-        if (!(__uint_as_float(gg.x << 16) > 0.f)) v[0] = 0.f;
-        if (!(__uint_as_float(gg.x & 0xffff0000u) > 0.f)) v[1] = 0.f;
-        if (!(__uint_as_float(gg.y << 16) > 0.f)) v[2] = 0.f;
-        if (!(__uint_as_float(gg.y & 0xffff0000u) > 0.f)) v[3] = 0.f;
+        const uint4 gg = *(const uint4*)((const bf16raw*)p.gate + coff + grow * p.ldg + tn0 + c8);
+        const unsigned w[4] = {gg.x, gg.y, gg.z, gg.w};
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          if (!(__uint_as_float(w[e] << 16) > 0.f)) v[2 * e] = 0.f;
+          if (!(__uint_as_float(w[e] & 0xffff0000u) > 0.f)) v[2 * e + 1] = 0.f;
+        }
       }
       if (OUTF32) {
-        float* C = (float*)p.C + coff + m * p.ldc + n;
-        if (p.flags & PERO_GEMM_ACCUM) {
-          const f4v o = *(const f4v*)C;
+        float* C = (float*)p.C + coff + grow * p.ldc + tn0 + c8;
+        if (p.flags & PERO_GEMM_ATOMIC) {
 #pragma unroll
-          for (int e = 0; e < 4; e++) v[e] += o[e];
+          for (int e = 0; e < 8; e++) atomicAdd(C + e, v[e]);
+        } else {
+          if (p.flags & PERO_GEMM_ACCUM) {
+            const f4v o0 = *(const f4v*)C, o1 = *(const f4v*)(C + 4);
+#pragma unroll
+            for (int e = 0; e < 4; e++) { v[e] += o0[e]; v[4 + e] += o1[e]; }
+          }
+          *(f4v*)C = (f4v){v[0], v[1], v[2], v[3]};
+          *(f4v*)(C + 4) = (f4v){v[4], v[5], v[6], v[7]};
         }
-        *(f4v*)C = (f4v){v[0], v[1], v[2], v[3]};
       } else {
-        uint2 o;
-        o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
-        *(uint2*)((bf16raw*)p.C + coff + m * p.ldc + n) = o;
+        uint4 o;
+        o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]); o.z = pack2bf(v[4], v[5]); o.w = pack2bf(v[6], v[7]);
+        *(uint4*)((bf16raw*)p.C + coff + grow * p.ldc + tn0 + c8) = o;
       }
     }
   }

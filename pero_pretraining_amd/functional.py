@@ -38,13 +38,60 @@ def linear_fwd(x, w, b, dtype, residual=None, relu=False, out_dtype=None):
                     out_dtype=out_dtype)
 
 
-def linear_bwd(dy, x, w, b, dtype, need_dx=True, gate=None, residual=None, bias_grad_done=False):
+SIDE_STREAM_DW = True  # weight / bias gradients on a second HIP stream (they are off the backward critical path)
+_side_streams = {}
+
+
+class SideStream:
+    """Runs the weight-gradient products of the backward pass on a second HIP stream: nothing downstream in the
+    backward chain reads them, so they can fill the tails / stalls of the dX chain's kernels.  Inputs are protected
+    from the caching allocator with record_stream; `join()` makes the main stream wait at the end."""
+
+    def __init__(self, device):
+        self.enabled = SIDE_STREAM_DW
+        self.main = torch.cuda.current_stream(device)
+        if self.enabled:
+            key = (device.index, self.main.cuda_stream)
+            if key not in _side_streams:
+                _side_streams[key] = torch.cuda.Stream(device=device)
+            self.side = _side_streams[key]
+            self.side.wait_stream(self.main)  # the gradient buffers were zeroed / touched on the main stream
+
+    def run(self, fn, *tensors):
+        """fn() launches kernels that read `tensors` (already produced on the main stream)."""
+        if not self.enabled:
+            fn()
+            return
+        ev = torch.cuda.Event()
+        ev.record(self.main)
+        self.side.wait_event(ev)
+        for t in tensors:
+            t.record_stream(self.side)
+        with torch.cuda.stream(self.side):
+            fn()
+
+    def stream_context(self):
+        return torch.cuda.stream(self.side) if self.enabled else torch.cuda.stream(self.main)
+
+    def join(self):
+        if self.enabled:
+            self.main.wait_stream(self.side)
+
+
+def linear_bwd(dy, x, w, b, dtype, need_dx=True, gate=None, residual=None, bias_grad_done=False, side=None):
     """dy (M,N), x (M,K), w (N,K).  Accumulates dW (+db) into .grad; returns dx = dy @ W (+residual)(*gate>0)."""
-    if w.requires_grad:
-        gw = ensure_grad(w)
-        ops.gemm(dy, x, out=gw.view(w.shape[0], -1), trans_a=True, trans_b=True, atomic=True, k_split=0)
-    if b is not None and b.requires_grad and not bias_grad_done:
-        ops.colsum(dy, ensure_grad(b))
+    def grads():
+        if w.requires_grad:
+            ops.gemm(dy, x, out=ensure_grad(w).view(w.shape[0], -1), trans_a=True, trans_b=True, atomic=True, k_split=0)
+        if b is not None and b.requires_grad and not bias_grad_done:
+            ops.colsum(dy, ensure_grad(b))
+    if side is not None:
+        ensure_grad(w)
+        if b is not None:
+            ensure_grad(b)
+        side.run(grads, dy, x)
+    else:
+        grads()
     if not need_dx:
         return None
     return ops.gemm(dy, lowp.weight(w, dtype).view(w.shape[0], -1), trans_b=True, residual=residual, gate=gate)
@@ -108,22 +155,22 @@ def layer_fwd(t, L, n, s, h, dtype, save):
     return t2, saved
 
 
-def layer_bwd(dt2, L, saved, n, s, h, dtype):
+def layer_bwd(dt2, L, saved, n, s, h, dtype, side=None):
     t, qkv, p, a, y1, mean1, rstd1, t1, hdn, y2, mean2, rstd2 = saved
     at = L.self_attn
     # LN2 (its dx column sums are linear2's bias gradient)
     dy2 = ops.layernorm_bwd(dt2, y2, mean2, rstd2, L.norm2.weight.detach(), ensure_grad(L.norm2.weight),
                             ensure_grad(L.norm2.bias), ensure_grad(L.linear2.bias))
-    dpre1 = linear_bwd(dy2, hdn, L.linear2.weight, L.linear2.bias, dtype, gate=hdn, bias_grad_done=True)
-    dt1 = linear_bwd(dpre1, t1, L.linear1.weight, L.linear1.bias, dtype, residual=dy2)
+    dpre1 = linear_bwd(dy2, hdn, L.linear2.weight, L.linear2.bias, dtype, gate=hdn, bias_grad_done=True, side=side)
+    dt1 = linear_bwd(dpre1, t1, L.linear1.weight, L.linear1.bias, dtype, residual=dy2, side=side)
     dy1 = ops.layernorm_bwd(dt1, y1, mean1, rstd1, L.norm1.weight.detach(), ensure_grad(L.norm1.weight),
                             ensure_grad(L.norm1.bias), ensure_grad(at.out_proj.bias))
-    da = linear_bwd(dy1, a, at.out_proj.weight, at.out_proj.bias, dtype, bias_grad_done=True)
+    da = linear_bwd(dy1, a, at.out_proj.weight, at.out_proj.bias, dtype, bias_grad_done=True, side=side)
     if p.dim() == 2:
         dqkv = ops.attention_bwd_fused(qkv, a, da, p, n, s, h)
     else:
         dqkv = attention_bwd(qkv, p, da, n, s, h)
-    return linear_bwd(dqkv, t, at.in_proj_weight, at.in_proj_bias, dtype, residual=dy1)
+    return linear_bwd(dqkv, t, at.in_proj_weight, at.in_proj_bias, dtype, residual=dy1, side=side)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -166,11 +213,13 @@ def backbone_fwd(mod, x, mask, offsets, dtype, save):
 def backbone_bwd(mod, saved, dt, dtype, on_layer_done=None):
     a0, y0, mean0, rstd0, layers, n, s = saved
     nl = len(layers)
+    side = SideStream(dt.device)
     for i in range(nl - 1, -1, -1):
-        dt = layer_bwd(dt, mod.encoder_layers.layers[i], layers[i], n, s, mod.num_heads, dtype)
+        dt = layer_bwd(dt, mod.encoder_layers.layers[i], layers[i], n, s, mod.num_heads, dtype, side)
         layers[i] = None
         if on_layer_done is not None:
-            on_layer_done(i)
+            with side.stream_context():  # the layer's last gradient kernels were enqueued on the side stream
+                on_layer_done(i)
     nrm = mod.intermediate_norm
     dy0 = ops.layernorm_bwd(dt, y0, mean0, rstd0, nrm.weight.detach(), ensure_grad(nrm.weight), ensure_grad(nrm.bias),
                             ensure_grad(mod.conv_layer.bias))
@@ -182,5 +231,6 @@ def backbone_bwd(mod, saved, dt, dtype, on_layer_done=None):
         tmp = torch.zeros((cw.shape[0], a0.shape[1]), device=a0.device, dtype=torch.float32)
         ops.gemm(dy0, a0, out=tmp, trans_a=True, trans_b=True, atomic=True, k_split=0)
         ops.add_rows2d(ensure_grad(cw).view(cw.shape[0], kp), tmp, kp)
+    side.join()
     if on_layer_done is not None:
         on_layer_done(-1)

@@ -18,8 +18,14 @@ def run(n):
         sched.update_learning_rate(i); trainer.train_step_prepared(*batches[i % 2])
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
 
+from pero_pretraining_amd import functional as F
 run(3)
-names = {0: "default (o128 simple)", 1: "t128 persistent", 2: "t256", 3: "s128 (4 WG/CU)", 6: "shape mix"}
+for flag in (True, False, True, False):
+    F.SIDE_STREAM_DW = flag
+    run(1)
+    print(f"side-stream dW {flag}: {run(4):.3f} ms/step")
+F.SIDE_STREAM_DW = True
+names = {0: "default s128+o128at", 3: "s128+t128p atomic", 4: "o128 all", 6: "shape mix"}
 res = {k: [] for k in names}
 for r in range(rounds):
     for pol in names:
