@@ -95,12 +95,27 @@ def cpu_baseline(budget_s=20.0, B=4):
             "sample": f"{n} steps of B={B} lines (40x2048, 12-layer d=512, f32) through oracle/pero_oracle.py MaskedStepOracle"}
 
 
+def pmc_traffic(batch):
+    """HBM bytes per GEMM launch from the committed rocprofv3 --pmc summary of this command (profiles/), if it was
+    collected for this batch size; None otherwise (bench.py cannot run the profiler on itself)."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_gemm_traffic.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        if int(d.get("lines_per_gpu", -1)) == int(batch):
+            return d.get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("PERO_BENCH_BATCH", 64)), help="lines per GPU")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("PERO_BENCH_BATCH", 128)), help="lines per GPU")
+    ap.add_argument("--no-side-stream", action="store_true", help="weight gradients on the main stream (clean per-kernel profiles)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -118,8 +133,11 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)
 
+    from pero_pretraining_amd import functional as F
     from pero_pretraining_amd import ops
     from pero_pretraining_amd.parallel import DataParallel
+    if args.no_side_stream:
+        F.SIDE_STREAM_DW = False
     bf16 = args.dtype == "bf16"
     model, opt, sched, trainer = build(device, bf16)
     if world > 1:
@@ -156,11 +174,18 @@ def main():
 
     roofline = None
     if not args.no_roofline:
+        # every GEMM launch of two extra steps bracketed by HIP events on the stream it is launched on; the weight
+        # gradients are put back on the main stream for this leg so that no two kernels share the chip while timed
+        side_was = F.SIDE_STREAM_DW
+        F.SIDE_STREAM_DW = False
+        step(args.warmup + args.steps)
+        torch.cuda.synchronize()
         ops.gemm_timeline = []
         for i in range(2):
-            step(args.warmup + args.steps + i)
+            step(args.warmup + args.steps + 1 + i)
         torch.cuda.synchronize()
         tl, ops.gemm_timeline = ops.gemm_timeline, None
+        F.SIDE_STREAM_DW = side_was
         per = {}
         for e0, e1, fl, tag in tl:
             d = per.setdefault(tag, [0.0, 0.0, 0])
@@ -174,7 +199,7 @@ def main():
         ach = fsum / tsum / 1e12
         roofline = {"bound": "mfma", "kernel": "gemm_bf16_t256 / gemm_bf16_t128 (bf16 tile GEMM, all operand layouts)", "achieved": round(ach, 2),
                     "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4),
-                    "traffic": None, "launches_per_step": nl // 2, "avg_launch_us": round(tsum / nl * 1e6, 2),
+                    "traffic": pmc_traffic(args.batch), "launches_per_step": nl // 2, "avg_launch_us": round(tsum / nl * 1e6, 2),
                     "gflop_per_launch": round(fsum / nl / 1e9, 3),
                     "gemm_time_share_of_step": round((tsum / 2) / (elapsed / args.steps), 3),
                     "by_layout": {k: {"tflops": round(v[1] / v[0] / 1e12, 1), "ms_per_step": round(v[0] / 2 * 1e3, 3),
@@ -194,6 +219,7 @@ def main():
                                    "(BASELINE.json configs[1])",
                        "lines_per_gpu": args.batch, "global_batch": args.batch * world, "seq_len": CFG["width"] // CFG["patch"],
                        "parallelism": f"dp{world}", "optimizer": "fused Adam (f32 master weights)",
+                       "weight_gradients_on_side_stream": bool(F.SIDE_STREAM_DW),
                        "gflop_per_line_step": round(step_flops / 1e9, 3)},
             "step_mfma_frac": round(lines_per_s / world * step_flops / (BF16_MFMA_PEAK_TFLOPS * 1e12), 4),
             "final_loss": round(final_loss, 5),

@@ -363,8 +363,12 @@ __global__ __launch_bounds__(256) void gemm_generic(GemmP p) {
 //   1 = persistent 128-tile with deferred epilogue, 2 = 256-tile, 3 = s128 + persistent for atomics, 4 = all o128,
 //   6 = shape-based mix of 2 and 3.
 static int g_gemm_policy = 0;
+static int g_splitk_items = 512;
+int g_pero_splitk_xcd = 1;  // one k-slice per XCD for split-K products (gemm_o.hip)  // work items the automatic split-K aims for (k_split = 0)
 extern "C" int pero_set_option(const char* name, int value) {
   if (name && !strcmp(name, "gemm_policy")) { g_gemm_policy = value; return PERO_OK; }
+  if (name && !strcmp(name, "splitk_xcd")) { g_pero_splitk_xcd = value; return PERO_OK; }
+  if (name && !strcmp(name, "splitk_items")) { g_splitk_items = value > 0 ? value : 512; return PERO_OK; }
   pero_set_error("pero_set_option: unknown option %s", name ? name : "(null)");
   return PERO_E_INVALID;
 }
@@ -414,9 +418,14 @@ extern "C" int pero_gemm(const void* A, const void* B, void* C, const float* bia
     bool use256 = false;
     (void)t256;
     if (atomic && k_split == 0) {
-      long long ks = (512 + t128 - 1) / t128;
+      long long ks = (g_splitk_items + t128 - 1) / t128;
       if (ks > K / 512) ks = K / 512;
       if (ks < 1) ks = 1;
+      // powers of two (<= 8) or multiples of 8: lets the kernel place one k-slice per XCD
+      if (ks >= 8) ks = ((ks + 7) / 8) * 8;
+      else if (ks > 4) ks = 8;
+      else if (ks == 3) ks = 4;
+      if (ks > K / 64) ks = 1;
       k_split = (int)ks;
     } else if (k_split < 1) {
       k_split = 1;

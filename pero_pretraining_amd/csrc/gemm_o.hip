@@ -63,7 +63,7 @@ __device__ __forceinline__ void ostage_glds(const bf16raw* X, long long ld, long
 }
 
 template <bool TA, bool TB, bool OUTF32>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_o128(GemmP p) {
+__global__ __launch_bounds__(256, 2) void gemm_bf16_o128(GemmP p, int ks_xcd) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -73,8 +73,20 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_o128(GemmP p) {
   const int ntn = (int)(p.N / O_BN);
   const int nt = (int)(p.M / O_BM) * ntn;
   const int bid = blockIdx.x;
-  const int q = nt >> 3, r8 = nt & 7, xcd = bid & 7, loc = bid >> 3;
-  const int id = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + loc;
+  int id, zslice;
+  if (ks_xcd > 0) {
+    // split-K products (weight gradients: the reduction runs over all tokens): put one k-slice per XCD, all of its
+    // output tiles on that XCD.  Every dY / X panel of the slice is then fetched from HBM once and re-read from that
+    // XCD's L2 by the other tiles (measured before: 408 MB fetched per launch for ~130 MB of unique operand bytes,
+    // because the tiles of one slice were spread over all 8 L2s).  Placement is a speed choice only.
+    const int xcd = bid & 7, r = bid >> 3;
+    if (ks_xcd >= 8) { const int per = ks_xcd >> 3; zslice = xcd * per + (r % per); id = r / per; }
+    else { zslice = xcd % ks_xcd; id = r * (8 / ks_xcd) + xcd / ks_xcd; }
+  } else {
+    const int q = nt >> 3, r8 = nt & 7, xcd = bid & 7, loc = bid >> 3;
+    id = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + loc;
+    zslice = blockIdx.z;
+  }
   const long long tm0 = (long long)(id / ntn) * O_BM, tn0 = (long long)(id % ntn) * O_BN;
 
   const int b = blockIdx.y;
@@ -83,7 +95,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_o128(GemmP p) {
   const bf16raw* B = (const bf16raw*)p.B + bo * p.sBo + bi * p.sBi;
   const long long coff = bo * p.sCo + bi * p.sCi;
 
-  const long long kbeg = (long long)blockIdx.z * p.kchunk;
+  const long long kbeg = (long long)zslice * p.kchunk;
   long long kend = kbeg + p.kchunk;
   if (kend > p.K) kend = p.K;
   const int nk = (int)((kend - kbeg) / O_BK);
@@ -220,6 +232,14 @@ bool pero_launch_gemm_o128(const GemmP& p0, long long batch, int k_split, bool t
     k_split = 1;
   }
   dim3 grid((unsigned)((p.M / O_BM) * (p.N / O_BN)), (unsigned)batch, (unsigned)k_split), block(256);
+  int ks_xcd = 0;
+  extern int g_pero_splitk_xcd;
+  const long long tiles = (p.M / O_BM) * (p.N / O_BN);
+  if (g_pero_splitk_xcd && batch == 1 && k_split > 1 && (k_split == 2 || k_split == 4 || k_split % 8 == 0) && (tiles * k_split) % 8 == 0 &&
+      (k_split >= 8 || tiles % (8 / k_split) == 0)) {
+    ks_xcd = k_split;
+    grid = dim3((unsigned)(tiles * k_split), 1, 1);
+  }
 #define LAUNCH_O(TA_, TB_, OF_)                                                                                           \
   do {                                                                                                                    \
     static bool attr_set = false;                                                                                         \
@@ -227,7 +247,7 @@ bool pero_launch_gemm_o128(const GemmP& p0, long long batch, int k_split, bool t
       hipFuncSetAttribute((const void*)gemm_bf16_o128<TA_, TB_, OF_>, hipFuncAttributeMaxDynamicSharedMemorySize, O_LDS_BYTES); \
       attr_set = true;                                                                                                    \
     }                                                                                                                     \
-    hipLaunchKernelGGL((gemm_bf16_o128<TA_, TB_, OF_>), grid, block, O_LDS_BYTES, st, p);                                 \
+    hipLaunchKernelGGL((gemm_bf16_o128<TA_, TB_, OF_>), grid, block, O_LDS_BYTES, st, p, ks_xcd);                                 \
   } while (0)
   if (!ta && !tb) { if (out_f32) LAUNCH_O(false, false, true); else LAUNCH_O(false, false, false); }
   else if (!ta && tb) { if (out_f32) LAUNCH_O(false, true, true); else LAUNCH_O(false, true, false); }

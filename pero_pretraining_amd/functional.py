@@ -49,6 +49,7 @@ class SideStream:
 
     def __init__(self, device):
         self.enabled = SIDE_STREAM_DW
+        self.keep = []
         self.main = torch.cuda.current_stream(device)
         if self.enabled:
             key = (device.index, self.main.cuda_stream)
@@ -58,15 +59,16 @@ class SideStream:
             self.side.wait_stream(self.main)  # the gradient buffers were zeroed / touched on the main stream
 
     def run(self, fn, *tensors):
-        """fn() launches kernels that read `tensors` (already produced on the main stream)."""
+        """fn() launches kernels that read `tensors` (already produced on the main stream).  The tensors are kept
+        alive until join() so that the caching allocator cannot hand their memory to a later main-stream allocation
+        while the side stream still reads it (this also holds under hipGraph capture, where record_stream does not)."""
         if not self.enabled:
             fn()
             return
         ev = torch.cuda.Event()
         ev.record(self.main)
         self.side.wait_event(ev)
-        for t in tensors:
-            t.record_stream(self.side)
+        self.keep.extend(tensors)
         with torch.cuda.stream(self.side):
             fn()
 
@@ -76,6 +78,7 @@ class SideStream:
     def join(self):
         if self.enabled:
             self.main.wait_stream(self.side)
+        self.keep = []
 
 
 def linear_bwd(dy, x, w, b, dtype, need_dx=True, gate=None, residual=None, bias_grad_done=False, side=None):

@@ -1,0 +1,58 @@
+"""VectorQuantizer with the interface of the reference's models/autoencoders.py:170-241 - the tokenizer step that
+produces the labels masked pre-training predicts (config 3: codebook 8192 x 512).  Inference path only (eval mode):
+nearest-code search by the fused exact-f32 HIP kernel (distances and one-hot matrices are never materialised),
+quantized output with the reference's straight-through arithmetic.  The EMA codebook update (training of the
+tokenizer itself, autoencoders.py:225-237) and the VGG encoder / decoder are outside the hot path."""
+import torch
+
+from .. import ops
+
+
+class VectorQuantizer(torch.nn.Module):
+    def __init__(self, num_embeddings, embeddings_dim, commitment_cost, decay, epsilon=1e-5):
+        super().__init__()
+        self.embeddings_dim = embeddings_dim
+        self.num_embeddings = num_embeddings
+        self.embedding = torch.nn.Embedding(self.num_embeddings, self.embeddings_dim)
+        if decay > 0.0:  # same parameter / buffer set and the same RNG draws as the reference constructor
+            self.embedding.weight.data.normal_()
+            self.register_buffer("ema_cluster_size", torch.zeros(num_embeddings))
+            self.ema_w = torch.nn.Parameter(torch.Tensor(num_embeddings, self.embeddings_dim))
+            self.ema_w.data.normal_()
+        else:
+            self.embedding.weight.data.uniform_(-1 / self.num_embeddings, 1 / self.num_embeddings)
+        self.commitment_cost = commitment_cost
+        self.decay = decay
+        self.epsilon = epsilon
+
+    def calculate_loss(self, tokens, features):
+        q_latent_loss = 0 if self.decay > 0.0 else torch.nn.functional.mse_loss(tokens, features.detach())
+        e_latent_loss = torch.nn.functional.mse_loss(tokens.detach(), features)
+        return q_latent_loss + self.commitment_cost * e_latent_loss
+
+    @torch.no_grad()
+    def nearest(self, flat_input):
+        """(M, D) float32 rows -> int64 indices of the nearest code (first minimum), bit-exact f32 arithmetic."""
+        if not flat_input.is_cuda:
+            raise RuntimeError("pero_pretraining_amd VectorQuantizer runs on the GPU only (HIP kernel, no CPU fallback)")
+        return ops.vq_argmin(flat_input.float().contiguous(), self.embedding.weight.detach().float().contiguous())
+
+    def forward(self, inputs):
+        """inputs (N, D, 1, T) -> (quantized (N, D, 1, T), indices (N*T,)) like autoencoders.py:204-241."""
+        if self.training and self.decay > 0.0:
+            raise NotImplementedError("EMA codebook training is outside the HIP hot path; call .eval() for label production")
+        x = inputs.permute(0, 2, 3, 1).contiguous()
+        shape = x.shape
+        flat = x.view(-1, self.embeddings_dim).float()
+        idx = self.nearest(flat)
+        q = ops.vq_gather(flat, self.embedding.weight.detach().float().contiguous(), idx).view(shape)
+        return q.permute(0, 3, 1, 2).contiguous(), idx
+
+
+def kmeans_labels(features, centroids):
+    """Feature-Quantization labels (scripts/produce_kmeans_labels.py:72-79): features (N, F, T), centroids (K, F)
+    -> (N, T) int64 assignments.  argmin of the true L2 distance == argmin of the squared expanded form used by the
+    kernel (up to exact ties)."""
+    n, f, t = features.shape
+    flat = features.permute(0, 2, 1).reshape(-1, f).float().contiguous()
+    return ops.vq_argmin(flat, centroids.float().contiguous()).view(n, t)

@@ -1,0 +1,102 @@
+"""GPU: the data-parallel training step with world_size 2 on ONE device (both ranks share cuda:0, gloo backend with
+device tensors - NCCL/RCCL needs one device per rank, which the test box does not have).  Checks the real model,
+FusedAdam flat buffers, the per-layer bucket hooks fired from the backbone's backward (on the side stream), gradient
+averaging via grad_scale, and that both ranks hold identical parameters after the step."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _build():
+    from pero_pretraining_amd.masked_pretraining import model as M
+    torch.manual_seed(0)
+    bb = M.init_backbone({"type": "vit", "num_blocks": 2, "model_dim": 64, "num_heads": 4, "feedforward_dim": 128})
+    hd = M.init_head({"type": "linear", "in_features": 64, "out_features": 96})
+    return M.MaskedTransformerEncoder(bb, hd).cuda().train()
+
+
+def _data(rank):
+    rng = np.random.default_rng(100 + rank)
+    images = rng.integers(0, 256, (3, 40, 128, 3), dtype=np.uint8)
+    labels = rng.integers(0, 96, (3, 16)).astype(np.int64)
+    mask = np.zeros((3, 16), np.int64)
+    mask[:, rank::3] = 1
+    return torch.from_numpy(images).cuda(), torch.from_numpy(labels).cuda(), torch.from_numpy(mask).cuda()
+
+
+def _worker(rank, world, port, out_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pero_pretraining_amd.common.lr_scheduler import WarmupSchleduler
+    from pero_pretraining_amd.masked_pretraining.trainer import Trainer
+    from pero_pretraining_amd.optim import FusedAdam
+    from pero_pretraining_amd.parallel import DataParallel
+    model = _build()
+    if rank == 1:  # different start: the constructor's broadcast must equalise
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(0.1)
+    opt = FusedAdam(model.parameters(), lr=1e-3)
+    dp = DataParallel(model, opt)
+    trainer = Trainer(None, model, None, opt, WarmupSchleduler(opt, 1e-3, 0, 1), data_parallel=dp)
+    offs = np.array([5, 17, 300]) + rank
+    model.backbone.set_offsets(offs)
+    images, labels, mask = _data(rank)
+    # forward/backward without the optimizer step to inspect the reduced gradients
+    loss = trainer._forward_backward(images, labels, mask)
+    torch.cuda.synchronize()
+    grads = {k: (p.grad * opt.grad_scale).cpu().numpy().copy() for k, p in model.named_parameters()}
+    opt.step()
+    torch.cuda.synchronize()
+    params = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu()
+    gathered = [torch.empty_like(params) for _ in range(world)]
+    dist.all_gather(gathered, params)
+    same = all(torch.equal(gathered[0], g) for g in gathered)
+    if rank == 0:
+        out_q.put((float(loss), grads, same))
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def test_two_rank_step_matches_mean_of_single_rank_gradients():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for port in [_free_port()] for r in range(2)]
+    for p in procs:
+        p.start()
+    loss0, grads, same = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert same, "ranks diverged after the optimizer step"
+    # reference: each rank's gradient computed alone in this process, averaged
+    ref = None
+    for rank in range(2):
+        model = _build()
+        model.backbone.set_offsets(np.array([5, 17, 300]) + rank)
+        images, labels, mask = _data(rank)
+        res = model(images, labels, mask)
+        res["loss"].backward()
+        if rank == 0:
+            assert abs(float(res["loss"]) - loss0) < 1e-6 * abs(loss0)
+        g = {k: p.grad.cpu().numpy() for k, p in model.named_parameters()}
+        ref = g if ref is None else {k: ref[k] + g[k] for k in g}
+    for k in ref:
+        want = ref[k] / 2
+        assert np.abs(grads[k] - want).max() <= 1e-5 * max(np.abs(want).max(), 1e-3), k

@@ -141,3 +141,36 @@ def test_mlp_head_matches_oracle_and_reference_layout():
     assert np.abs(xg.grad.cpu().numpy() - xr.grad.numpy()).max() < 1e-3
     for k, p in head.named_parameters():
         assert np.abs(p.grad.cpu().numpy() - gref[k].numpy()).max() < 1e-3 * max(1.0, float(gref[k].abs().max())), k
+
+
+def test_vector_quantizer_module_matches_reference_golden(golden):
+    """Config 3 tokenizer: VectorQuantizer(8192, 512) from the reference's seed recipe, indices bit-exact (outside
+    recorded near-ties), quantized output bit-exact for the small codebook; k-means label helper."""
+    from pero_pretraining_amd.models.autoencoders import VectorQuantizer, kmeans_labels
+    g = golden("g6_quantizers.npz")
+    torch.manual_seed(5)
+    vq = VectorQuantizer(8192, 512, 0.25, 0.99)
+    assert abs(float(vq.embedding.weight.double().sum()) - float(g["cb8192.codebook_checksum"])) < 1e-6
+    assert set(vq.state_dict().keys()) == {"ema_w", "ema_cluster_size", "embedding.weight"}
+    vq = vq.cuda().eval()
+    q, idx = vq(cu(g["cb8192.features"]))
+    near_tie = (g["cb8192.second"] - g["cb8192.best"]) < 1e-4 * np.abs(g["cb8192.best"])
+    got = idx.cpu().numpy()
+    assert np.array_equal(got[~near_tie], g["cb8192.indices"][~near_tie])
+    assert q.shape == g["cb8192.features"].shape
+    same = got == g["cb8192.indices"]
+    qs = q[:, :8, :, :8].cpu().numpy()
+    ok_cols = same.reshape(2, -1)[:, :8]
+    assert np.array_equal(qs[np.broadcast_to(ok_cols[:, None, None, :], qs.shape)],
+                          g["cb8192.quantized_sample"][np.broadcast_to(ok_cols[:, None, None, :], qs.shape)])
+    torch.manual_seed(5)
+    small = VectorQuantizer(64, 32, 0.25, 0.99)
+    small.embedding.weight.data.copy_(torch.from_numpy(g["small.codebook"]))
+    small = small.cuda().eval()
+    q2, idx2 = small(cu(g["small.features"]))
+    assert np.array_equal(idx2.cpu().numpy(), g["small.indices"])
+    assert np.array_equal(q2[:, :8, :, :8].cpu().numpy(), g["small.quantized_sample"])
+    km = kmeans_labels(cu(g["small.features"][:, :, 0, :]), cu(g["small.codebook"]))
+    assert np.array_equal(km.cpu().numpy().reshape(-1), g["small.kmeans_indices"])
+    with pytest.raises(NotImplementedError):
+        small.train()(cu(g["small.features"]))

@@ -20,10 +20,24 @@ def run(n):
 
 from pero_pretraining_amd import functional as F
 run(3)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for i in range(4):
+    sched.update_learning_rate(i); trainer.train_step_prepared(*batches[i % 2])
+t_host = (time.perf_counter() - t0) / 4 * 1e3
+torch.cuda.synchronize()
+print(f"host enqueue time per step: {t_host:.3f} ms (GPU step below)")
 for flag in (True, False, True, False):
     F.SIDE_STREAM_DW = flag
     run(1)
     print(f"side-stream dW {flag}: {run(4):.3f} ms/step")
+F.SIDE_STREAM_DW = True
+for v in (1, 0, 1, 0):
+    _lib.lib().pero_set_option(b"splitk_xcd", v)
+    for ss in (True, False):
+        F.SIDE_STREAM_DW = ss
+        run(1)
+        print(f"split-K slice-per-XCD {v} side-stream {ss}: {run(4):.3f} ms/step")
+_lib.lib().pero_set_option(b"splitk_xcd", 1)
 F.SIDE_STREAM_DW = True
 names = {0: "default s128+o128at", 3: "s128+t128p atomic", 4: "o128 all", 6: "shape mix"}
 res = {k: [] for k in names}
