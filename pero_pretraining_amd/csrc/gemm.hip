@@ -430,9 +430,17 @@ extern "C" int pero_gemm(const void* A, const void* B, void* C, const float* bia
     } else if (k_split < 1) {
       k_split = 1;
     }
-    if (!forced0 && (g_gemm_policy == 4 || (g_gemm_policy == 0 && atomic)) &&
+    if (!forced0 && (g_gemm_policy == 4 || ((g_gemm_policy == 0 || g_gemm_policy >= 7) && atomic)) &&
         pero_launch_gemm_o128(p, batch, k_split, ta, tb, out_dtype == PERO_F32, st)) {
       PERO_CHECK_LAUNCH("pero_gemm(bf16 o128)");
+      return PERO_OK;
+    }
+    if (g_gemm_policy == 8 && !forced0 && !atomic && pero_launch_gemm_q256(p, batch, k_split, ta, tb, out_dtype == PERO_F32, st)) {
+      PERO_CHECK_LAUNCH("pero_gemm(bf16 q256)");
+      return PERO_OK;
+    }
+    if (g_gemm_policy == 7 && !forced0 && !atomic && pero_launch_gemm_r256(p, batch, k_split, ta, tb, out_dtype == PERO_F32, st)) {
+      PERO_CHECK_LAUNCH("pero_gemm(bf16 r256)");
       return PERO_OK;
     }
     if (flags & PERO_GEMM_TILE256) use256 = can256;
@@ -442,7 +450,7 @@ extern "C" int pero_gemm(const void* A, const void* B, void* C, const float* bia
     if (!forced && !atomic) {
       if (K >= 2048 && t256 >= 192 && !tb) use256 = true;
     }
-    if (g_gemm_policy == 0) use256 = (flags & PERO_GEMM_TILE256) && can256;
+    if (g_gemm_policy == 0 || g_gemm_policy >= 7) use256 = (flags & PERO_GEMM_TILE256) && can256;
     if (((flags & PERO_GEMM_TILE_S) || (!forced && !use256)) && !atomic &&
         pero_launch_gemm_s128(p, batch, k_split, ta, tb, out_dtype == PERO_F32, st)) {
       PERO_CHECK_LAUNCH("pero_gemm(bf16 s128)");

@@ -32,3 +32,7 @@ bool pero_launch_gemm_t256(const GemmP& p, long long batch, int k_split, bool ta
 bool pero_launch_gemm_s128(const GemmP& p, long long batch, int k_split, bool ta, bool tb, bool out_f32, hipStream_t st);
 // host entry of the simple one-tile-per-workgroup 128x128x64 kernel (gemm_o.hip)
 bool pero_launch_gemm_o128(const GemmP& p, long long batch, int k_split, bool ta, bool tb, bool out_f32, hipStream_t st);
+// host entry of the 256x128x32 eight-wave kernel (gemm_r.hip)
+bool pero_launch_gemm_r256(const GemmP& p, long long batch, int k_split, bool ta, bool tb, bool out_f32, hipStream_t st);
+// host entry of the 256x256x32 sixteen-wave kernel (gemm_q.hip)
+bool pero_launch_gemm_q256(const GemmP& p, long long batch, int k_split, bool ta, bool tb, bool out_f32, hipStream_t st);

@@ -1,8 +1,8 @@
-// 128 x 128 x 32 bf16 tile GEMM tuned for OCCUPANCY (gfx950): 32 KiB of LDS and <= 128 VGPRs per workgroup, so four
-// workgroups (16 waves) share a CU.  Motivation (measured on the step's shapes): vmcnt counts stores in issue order, so
+// 128 x 128 x 32 bf16 tile GEMM tuned for OCCUPANCY and bytes in flight (gfx950): 48 KiB of LDS (3-slot LDS-DMA ring)
+// and <= 168 VGPRs per workgroup, so three workgroups (12 waves) share a CU.  Motivation (measured on the step's shapes): vmcnt counts stores in issue order, so
 // a wave that has issued its tile's stores cannot get past its next LDS-DMA wait until they reached HBM; neither
 // persistence + prefetch nor deferring the stores into the next main loop hid that (both measured slower or equal).
-// What hides it is other resident workgroups: while one drains its stores, three others run their main loops.
+// What hides it is other resident workgroups: while one drains its stores, the others run their main loops.
 // Same contract / operand images as gemm_bf16_t128, BK = 32 (one MFMA k-step per LDS tile), epilogue staged
 // through LDS in two 64-row halves.
 #include "gemm_common.hpp"
@@ -13,7 +13,8 @@
 #define S_OPBYTES (128 * 32 * 2)     // 8 KiB per operand tile
 #define S_BUFBYTES (2 * S_OPBYTES)   // 16 KiB per stage
 #define S_EPI_PITCH 528                // f32 staging pitch (128 * 4 + 16)
-#define S_LDS_BYTES (64 * S_EPI_PITCH) // 33792 B >= 2 * S_BUFBYTES (32 KiB): four workgroups per CU
+#define S_STAGES 3                     // LDS ring: two k-tiles in flight behind the one being multiplied
+#define S_LDS_BYTES (S_STAGES * S_BUFBYTES) // 48 KiB (>= 33792 B of epilogue staging): three workgroups per CU
 
 // K-contiguous image [128 rows][32 k] = 64-byte rows, 4 chunks of 16 B, four rows per 256-byte bank row.  A
 // ds_read_b128 is served in the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... (MI355X_MICROARCH.md, LDS):
@@ -58,8 +59,20 @@ __device__ __forceinline__ void sstage_glds(const bf16raw* X, long long ld, long
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p + step), (__attribute__((address_space(3))) void*)(dst + 4096), 16, 0, 0);
 }
 
+#ifdef PERO_GEMM_STAMP
+// diagnostic build only (make EXTRA=-DPERO_GEMM_STAMP): where does a wave's k-step go?  Cycle sums per phase, added
+// by lane 0 of every wave; read back with pero_debug_read_stamps.  Never quote this build's run time.
+__device__ unsigned long long g_pero_stamp[8];
+#define STAMP(var) do { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); } while (0)
+extern "C" int pero_debug_read_stamps(unsigned long long* out8, int reset) {
+  hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_pero_stamp), 64);
+  if (reset) { unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_pero_stamp), z, 64); }
+  return 0;
+}
+#endif
+
 template <bool TA, bool TB, bool OUTF32>
-__global__ __launch_bounds__(256, 4) void gemm_bf16_s128(GemmP p) {
+__global__ __launch_bounds__(256, 3) void gemm_bf16_s128(GemmP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -85,32 +98,73 @@ __global__ __launch_bounds__(256, 4) void gemm_bf16_s128(GemmP p) {
 #pragma unroll
     for (int j = 0; j < 4; j++) acc[i][j] = (f4v){0.f, 0.f, 0.f, 0.f};
 
+  // L2 -> LDS throughput is set by the bytes in flight per CU (~70 KB in flight deliver ~33 B/clk/CU, guide "gather
+  // into LDS"), not by issue: a 3-slot ring keeps TWO k-tiles in flight per workgroup (3 workgroups x 32 KiB = 96 KiB
+  // per CU instead of 64 KiB with a double buffer).  Counted vmcnt (the newest tile's 4 DMAs stay outstanding) and a raw
+  // s_barrier: a __syncthreads() would drain vmcnt(0).
   if (nk > 0) {
     sstage_glds<TA>(A, p.lda, tm0, kbeg, smem, tid);
     sstage_glds<TB>(B, p.ldb, tn0, kbeg, smem + S_OPBYTES, tid);
   }
+  if (nk > 1) {
+    sstage_glds<TA>(A, p.lda, tm0, kbeg + S_BK, smem + S_BUFBYTES, tid);
+    sstage_glds<TB>(B, p.ldb, tn0, kbeg + S_BK, smem + S_BUFBYTES + S_OPBYTES, tid);
+  }
+  int slot = 0;
+#ifdef PERO_GEMM_STAMP
+  unsigned long long st0, st1, st2, st3, st4, st5, acc_w = 0, acc_b = 0, acc_g = 0, acc_r = 0, acc_m = 0;
+#endif
   for (int t = 0; t < nk; t++) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    const unsigned char* sa = smem + (t & 1) * S_BUFBYTES;
+#ifdef PERO_GEMM_STAMP
+    __builtin_amdgcn_sched_barrier(0); STAMP(st0); __builtin_amdgcn_sched_barrier(0);
+#endif
+    if (t + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef PERO_GEMM_STAMP
+    __builtin_amdgcn_sched_barrier(0); STAMP(st1); __builtin_amdgcn_sched_barrier(0);
+#endif
+    lds_barrier();  // tile t visible to all waves; all waves are past their reads of slot (t + 2) % 3
+#ifdef PERO_GEMM_STAMP
+    __builtin_amdgcn_sched_barrier(0); STAMP(st2); __builtin_amdgcn_sched_barrier(0);
+#endif
+    const unsigned char* sa = smem + slot * S_BUFBYTES;
     const unsigned char* sb = sa + S_OPBYTES;
-    if (t + 1 < nk) {
-      unsigned char* da = smem + ((t + 1) & 1) * S_BUFBYTES;
-      sstage_glds<TA>(A, p.lda, tm0, kbeg + (long long)(t + 1) * S_BK, da, tid);
-      sstage_glds<TB>(B, p.ldb, tn0, kbeg + (long long)(t + 1) * S_BK, da + S_OPBYTES, tid);
+    if (t + 2 < nk) {
+      const int ns = slot >= 1 ? slot - 1 : 2;  // (slot + 2) % 3
+      unsigned char* da = smem + ns * S_BUFBYTES;
+      sstage_glds<TA>(A, p.lda, tm0, kbeg + (long long)(t + 2) * S_BK, da, tid);
+      sstage_glds<TB>(B, p.ldb, tn0, kbeg + (long long)(t + 2) * S_BK, da + S_OPBYTES, tid);
     }
+    slot = slot == 2 ? 0 : slot + 1;
+#ifdef PERO_GEMM_STAMP
+    __builtin_amdgcn_sched_barrier(0); STAMP(st3); __builtin_amdgcn_sched_barrier(0);
+#endif
     bf8v fa[4], fb[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       fa[i] = TA ? sfrag_kmajor(sa, wm * 64 + i * 16, lane) : sfrag_rowmajor(sa, wm * 64 + i * 16, lane);
       fb[i] = TB ? sfrag_kmajor(sb, wn * 64 + i * 16, lane) : sfrag_rowmajor(sb, wn * 64 + i * 16, lane);
     }
+#ifdef PERO_GEMM_STAMP
+    __builtin_amdgcn_sched_barrier(0); STAMP(st4); __builtin_amdgcn_sched_barrier(0);  // the stamp's lgkmcnt(0) = fragments landed
+#endif
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
       for (int j = 0; j < 4; j++)
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+#ifdef PERO_GEMM_STAMP
+    asm volatile("s_nop 15\n\ts_nop 15" ::"v"(acc[3][3]));  // MFMA results consumed: the chain has drained
+    __builtin_amdgcn_sched_barrier(0); STAMP(st5); __builtin_amdgcn_sched_barrier(0);
+    acc_w += st1 - st0; acc_b += st2 - st1; acc_g += st3 - st2; acc_r += st4 - st3; acc_m += st5 - st4;
+#endif
   }
+#ifdef PERO_GEMM_STAMP
+  if (lane == 0) {
+    atomicAdd(&g_pero_stamp[0], acc_w); atomicAdd(&g_pero_stamp[1], acc_b); atomicAdd(&g_pero_stamp[2], acc_g);
+    atomicAdd(&g_pero_stamp[3], acc_r); atomicAdd(&g_pero_stamp[4], acc_m); atomicAdd(&g_pero_stamp[5], (unsigned long long)nk);
+  }
+#endif
 
   // ---- epilogue: f32 accumulators -> LDS in two 64-row halves -> whole 256-byte row segments to HBM (16-byte lanes).
   // In-step A/B showed that full-line coalesced stores (and 16-byte residual / gate loads) matter more than the
@@ -121,7 +175,7 @@ __global__ __launch_bounds__(256, 4) void gemm_bf16_s128(GemmP p) {
   for (int e = 0; e < 8; e++) bias[e] = p.bias ? p.bias[tn0 + c8 + e] : 0.f;
 #pragma unroll
   for (int half = 0; half < 2; half++) {
-    __syncthreads();  // main-loop reads (half 0) / previous half's staging reads (half 1) are done
+    lds_barrier();  // main-loop reads (half 0) / previous half's staging reads (half 1) are done
     if (wm == half) {
 #pragma unroll
       for (int i = 0; i < 4; i++)
@@ -129,7 +183,7 @@ __global__ __launch_bounds__(256, 4) void gemm_bf16_s128(GemmP p) {
         for (int j = 0; j < 4; j++)
           *(f4v*)(smem + (i * 16 + (lane & 15)) * S_EPI_PITCH + (wn * 64 + j * 16 + (lane >> 4) * 4) * 4) = acc[i][j];
     }
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int rr = 0; rr < 4; rr++) {
       const int row = (tid >> 4) + 16 * rr;

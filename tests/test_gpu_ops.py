@@ -137,6 +137,33 @@ def test_gemm_bf16_s128_layouts_and_epilogues(ops, ta, tb):
     assert rel_err(out, full) < 2 ** -8
 
 
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("policy", [7, 8])
+def test_gemm_bf16_r256_layouts_and_epilogues(ops, ta, tb, policy):
+    """256x128x32 eight-wave (policy 7) and 256x256x32 sixteen-wave (policy 8) kernels: exact integers in all
+    layouts + the fused epilogue."""
+    from pero_pretraining_amd import _lib
+    M, N, K = 768, 512, 160
+    g = torch.Generator().manual_seed(14)
+    a = torch.randint(-3, 4, (K, M) if ta else (M, K), generator=g).float()
+    b = torch.randint(-3, 4, (K, N) if tb else (N, K), generator=g).float()
+    ref = (a.t() if ta else a) @ (b.t() if tb else b).t()
+    _lib.lib().pero_set_option(b"gemm_policy", policy)
+    try:
+        for od in (torch.bfloat16, torch.float32):
+            out = ops.gemm(dev(a, torch.bfloat16), dev(b, torch.bfloat16), trans_a=ta, trans_b=tb, out_dtype=od)
+            assert torch.equal(out.float().cpu(), ref.to(od).float())
+        bias = torch.randn(N, generator=g)
+        res = torch.randn(M, N, generator=g).bfloat16()
+        gate = torch.randn(M, N, generator=g).bfloat16()
+        full = torch.relu(0.5 * ref.double() + bias.double() + res.double()) * (gate.double() > 0)
+        out = ops.gemm(dev(a, torch.bfloat16), dev(b, torch.bfloat16), trans_a=ta, trans_b=tb, bias=dev(bias), residual=dev(res),
+                       gate=dev(gate), relu=True, alpha=0.5)
+        assert rel_err(out, full) < 2 ** -8
+    finally:
+        _lib.lib().pero_set_option(b"gemm_policy", 0)
+
+
 def test_gemm_bf16_tile256_epilogues_splitk_and_persistence(ops):
     from pero_pretraining_amd._lib import GEMM_TILE256
     M, N, K = 256 * 70, 512, 256   # 140 tiles... still < CUs; plus a > CU-count case below
