@@ -357,11 +357,11 @@ __global__ __launch_bounds__(256) void gemm_generic(GemmP p) {
 // ------------------------------------------------------------------------------------------------
 // Tile-kernel policy, chosen by interleaved same-process A/B of the WHOLE training step (tools/step_ab.py; isolated
 // hot-cache micro-benchmarks ranked the variants differently, and devices differ by ~10 % between runs):
-//   0 = default: products with a stored output -> gemm_bf16_s128 (128x128x32, four workgroups per CU, LDS-staged
-//       coalesced epilogue); split-K atomic products (weight gradients) -> gemm_bf16_o128 (128x128x64, one tile per
-//       workgroup).  17.3 ms / step at 128 lines vs 17.9 (all o128), 19.2-21.9 (persistent / 256-tile variants).
-//   1 = persistent 128-tile with deferred epilogue, 2 = 256-tile, 3 = s128 + persistent for atomics, 4 = all o128,
-//   6 = shape-based mix of 2 and 3.
+//   0 = default: products with a stored output -> gemm_bf16_r256 (256x128x32, 8 waves, two workgroups per CU) when M is a
+//       multiple of 256, else gemm_bf16_s128 (128x128x32, three workgroups per CU); split-K atomic products (weight
+//       gradients) -> gemm_bf16_o128 (128x128x64, one tile per workgroup).  16.3 ms / step at 128 lines.
+//   1 = persistent 128-tile with deferred epilogue (20.7), 2 = 256-tile 8 waves (21.9), 3 = s128 (17.1), 4 = all o128
+//   (16.9), 6 = shape mix of 2/3, 7 = r256, 8 = q256 16-wave 256x256x32 (16.7), 9 = p128 software-pipelined (18.3).
 static int g_gemm_policy = 0;
 static int g_splitk_items = 512;
 int g_pero_splitk_xcd = 1;  // one k-slice per XCD for split-K products (gemm_o.hip)  // work items the automatic split-K aims for (k_split = 0)
@@ -435,11 +435,15 @@ extern "C" int pero_gemm(const void* A, const void* B, void* C, const float* bia
       PERO_CHECK_LAUNCH("pero_gemm(bf16 o128)");
       return PERO_OK;
     }
+    if (g_gemm_policy == 9 && !forced0 && !atomic && pero_launch_gemm_p128(p, batch, k_split, ta, tb, out_dtype == PERO_F32, st)) {
+      PERO_CHECK_LAUNCH("pero_gemm(bf16 p128)");
+      return PERO_OK;
+    }
     if (g_gemm_policy == 8 && !forced0 && !atomic && pero_launch_gemm_q256(p, batch, k_split, ta, tb, out_dtype == PERO_F32, st)) {
       PERO_CHECK_LAUNCH("pero_gemm(bf16 q256)");
       return PERO_OK;
     }
-    if (g_gemm_policy == 7 && !forced0 && !atomic && pero_launch_gemm_r256(p, batch, k_split, ta, tb, out_dtype == PERO_F32, st)) {
+    if ((g_gemm_policy == 7 || g_gemm_policy == 0) && !forced0 && !atomic && pero_launch_gemm_r256(p, batch, k_split, ta, tb, out_dtype == PERO_F32, st)) {
       PERO_CHECK_LAUNCH("pero_gemm(bf16 r256)");
       return PERO_OK;
     }

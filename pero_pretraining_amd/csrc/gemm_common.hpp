@@ -36,3 +36,5 @@ bool pero_launch_gemm_o128(const GemmP& p, long long batch, int k_split, bool ta
 bool pero_launch_gemm_r256(const GemmP& p, long long batch, int k_split, bool ta, bool tb, bool out_f32, hipStream_t st);
 // host entry of the 256x256x32 sixteen-wave kernel (gemm_q.hip)
 bool pero_launch_gemm_q256(const GemmP& p, long long batch, int k_split, bool ta, bool tb, bool out_f32, hipStream_t st);
+// host entry of the software-pipelined 128x128x32 kernel (gemm_p.hip)
+bool pero_launch_gemm_p128(const GemmP& p, long long batch, int k_split, bool ta, bool tb, bool out_f32, hipStream_t st);

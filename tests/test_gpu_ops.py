@@ -138,7 +138,7 @@ def test_gemm_bf16_s128_layouts_and_epilogues(ops, ta, tb):
 
 
 @pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
-@pytest.mark.parametrize("policy", [7, 8])
+@pytest.mark.parametrize("policy", [7, 8, 9])
 def test_gemm_bf16_r256_layouts_and_epilogues(ops, ta, tb, policy):
     """256x128x32 eight-wave (policy 7) and 256x256x32 sixteen-wave (policy 8) kernels: exact integers in all
     layouts + the fused epilogue."""

@@ -39,7 +39,7 @@ for v in (1, 0, 1, 0):
         print(f"split-K slice-per-XCD {v} side-stream {ss}: {run(4):.3f} ms/step")
 _lib.lib().pero_set_option(b"splitk_xcd", 1)
 F.SIDE_STREAM_DW = True
-names = {0: "default s128+o128at", 7: "r256 (256x128x32)+o128at", 8: "q256 (256x256x32,16w)", 4: "o128 all"}
+names = {0: "default r256|s128 +o128at", 9: "p128 sw-pipelined 3 slots", 3: "s128", 4: "o128 all"}
 res = {k: [] for k in names}
 for r in range(rounds):
     for pol in names:
