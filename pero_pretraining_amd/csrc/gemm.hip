@@ -368,7 +368,7 @@ int g_pero_splitk_xcd = 1;  // one k-slice per XCD for split-K products (gemm_o.
 extern "C" int pero_set_option(const char* name, int value) {
   if (name && !strcmp(name, "gemm_policy")) { g_gemm_policy = value; return PERO_OK; }
   if (name && !strcmp(name, "splitk_xcd")) { g_pero_splitk_xcd = value; return PERO_OK; }
-  if (name && !strcmp(name, "splitk_items")) { g_splitk_items = value > 0 ? value : 512; return PERO_OK; }
+  if (name && !strcmp(name, "splitk_items")) { g_splitk_items = value > 0 ? value : 256; return PERO_OK; }
   pero_set_error("pero_set_option: unknown option %s", name ? name : "(null)");
   return PERO_E_INVALID;
 }

@@ -282,22 +282,6 @@ extern "C" int pero_softmax_bwd(const void* p, const float* dp, void* ds, int64_
 // masked cross entropy.  work[0..rows) = per-row loss, work[rows+0] = n_masked, work[rows+1] = n_unmasked,
 // work[rows+8 .. 2*rows+8) = per-row logsumexp (kept for the backward kernel)
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ce_count_k(const int64_t* labels, const int64_t* mask, float* work, long long rows) {
-  __shared__ int sm[2][4];
-  int nm = 0, nu = 0;
-  for (long long r = threadIdx.x; r < rows; r += 256) {
-    if (mask[r] == 1) nm++;
-    else if (mask[r] == 0 && labels[r] >= 0) nu++;
-  }
-  nm = (int)wave_sum((float)nm);  // exact: counts < 2^24
-  nu = (int)wave_sum((float)nu);
-  if ((threadIdx.x & 63) == 0) { sm[0][threadIdx.x >> 6] = nm; sm[1][threadIdx.x >> 6] = nu; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    work[rows] = (float)(sm[0][0] + sm[0][1] + sm[0][2] + sm[0][3]);
-    work[rows + 1] = (float)(sm[1][0] + sm[1][1] + sm[1][2] + sm[1][3]);
-  }
-}
 // forward: per-row loss -> work[row], per-row logsumexp -> work[rows + 8 + row]
 template <typename T>
 __global__ __launch_bounds__(256) void ce_rows_k(const T* logits, const int64_t* labels, const int64_t* mask, float uw,
@@ -354,20 +338,30 @@ __global__ __launch_bounds__(256) void ce_bwd_k(const T* logits, const int64_t* 
     Elem<T>::st(dlogits + row * V + c, g * w);
   }
 }
-__global__ __launch_bounds__(256) void ce_final_k(const int64_t* labels, const int64_t* mask, float uw, const float* work,
-                                                  float* loss, long long rows) {
-  __shared__ float sm[2][4];
-  float a = 0.f, b = 0.f;  // fixed summation order: deterministic
-  for (long long r = threadIdx.x; r < rows; r += 256) {
-    if (mask[r] == 1) a += work[r];
-    else if (mask[r] == 0 && labels[r] >= 0) b += work[r];
+// counts + deterministic loss sums in one pass (1024 threads, fixed order): work[rows] = n_masked,
+// work[rows+1] = n_unmasked (read by the backward kernel), loss = sum_m/n_m (+ uw * sum_u/n_u)
+__global__ __launch_bounds__(1024) void ce_final_k(const int64_t* labels, const int64_t* mask, float uw, float* work,
+                                                   float* loss, long long rows) {
+  __shared__ float sm[4][16];
+  float a = 0.f, b = 0.f, na = 0.f, nb = 0.f;
+  for (long long r = threadIdx.x; r < rows; r += 1024) {
+    const long long mk = mask[r], lb = labels[r];
+    const float w = work[r];
+    if (mk == 1) { a += w; na += 1.f; }
+    else if (mk == 0 && lb >= 0) { b += w; nb += 1.f; }
   }
-  a = wave_sum(a); b = wave_sum(b);
-  if ((threadIdx.x & 63) == 0) { sm[0][threadIdx.x >> 6] = a; sm[1][threadIdx.x >> 6] = b; }
+  a = wave_sum(a); b = wave_sum(b); na = wave_sum(na); nb = wave_sum(nb);
+  const int wv = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { sm[0][wv] = a; sm[1][wv] = b; sm[2][wv] = na; sm[3][wv] = nb; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    float l = ((sm[0][0] + sm[0][1]) + (sm[0][2] + sm[0][3])) / work[rows];
-    if (uw >= 0.f) l += uw * (((sm[1][0] + sm[1][1]) + (sm[1][2] + sm[1][3])) / work[rows + 1]);
+    float t[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < 4; q++)
+      for (int i = 0; i < 16; i++) t[q] += sm[q][i];
+    work[rows] = t[2];
+    work[rows + 1] = t[3];
+    float l = t[0] / t[2];
+    if (uw >= 0.f) l += uw * (t[1] / t[3]);
     loss[0] = l;
   }
 }
@@ -376,11 +370,10 @@ extern "C" int pero_masked_ce_fwd(const void* logits, const int64_t* labels, con
   PERO_REQUIRE(logits && labels && mask && loss_out && work, "pero_masked_ce_fwd: null pointer");
   PERO_REQUIRE(rows > 0 && V > 0 && rows < 16777216, "pero_masked_ce_fwd: bad sizes");
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(ce_count_k, dim3(1), dim3(256), 0, st, labels, mask, work, (long long)rows);
   if (dtype == PERO_F32) hipLaunchKernelGGL((ce_rows_k<float>), dim3((unsigned)rows), dim3(256), 0, st, (const float*)logits, labels, mask, unmasked_weight, work, (long long)rows, (int)V);
   else if (dtype == PERO_BF16) hipLaunchKernelGGL((ce_rows_k<bf16raw>), dim3((unsigned)rows), dim3(256), 0, st, (const bf16raw*)logits, labels, mask, unmasked_weight, work, (long long)rows, (int)V);
   else PERO_REQUIRE(false, "pero_masked_ce_fwd: bad dtype");
-  hipLaunchKernelGGL(ce_final_k, dim3(1), dim3(256), 0, st, labels, mask, unmasked_weight, work, loss_out, (long long)rows);
+  hipLaunchKernelGGL(ce_final_k, dim3(1), dim3(1024), 0, st, labels, mask, unmasked_weight, work, loss_out, (long long)rows);
   PERO_CHECK_LAUNCH("pero_masked_ce_fwd");
   return PERO_OK;
 }

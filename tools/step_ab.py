@@ -31,14 +31,15 @@ for flag in (True, False, True, False):
     run(1)
     print(f"side-stream dW {flag}: {run(4):.3f} ms/step")
 F.SIDE_STREAM_DW = True
-for v in (1, 0, 1, 0):
-    _lib.lib().pero_set_option(b"splitk_xcd", v)
-    for ss in (True, False):
-        F.SIDE_STREAM_DW = ss
-        run(1)
-        print(f"split-K slice-per-XCD {v} side-stream {ss}: {run(4):.3f} ms/step")
-_lib.lib().pero_set_option(b"splitk_xcd", 1)
-F.SIDE_STREAM_DW = True
+for nst, items in ((1, 512), (2, 512), (2, 256), (4, 256), (4, 128), (1, 512), (2, 256), (4, 256)):
+    F.SIDE_STREAMS = nst
+    F._side_streams.clear()
+    _lib.lib().pero_set_option(b"splitk_items", items)
+    run(1)
+    print(f"side streams {nst} split-K items {items}: {run(4):.3f} ms/step")
+F.SIDE_STREAMS = 2
+F._side_streams.clear()
+_lib.lib().pero_set_option(b"splitk_items", 256)
 names = {0: "default r256|s128 +o128at", 9: "p128 sw-pipelined 3 slots", 3: "s128", 4: "o128 all"}
 res = {k: [] for k in names}
 for r in range(rounds):
