@@ -93,6 +93,110 @@ __global__ __launch_bounds__(256) void vq_argmin_k(const float* x, const float* 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Fast path (K % 128 == 0, D % 32 == 0, M % 64 == 0): 64 feature rows x 128 codes x 32 depth per stage, tiles
+// staged by LDS-DMA into a double buffer (24 KiB per stage, three workgroups per CU), fragments read with ds_read_b128
+// (4 consecutive depth values per lane: MFMA step e multiplies depth 8j+e on lanes 0-31 and 8j+4+e on lanes 32-63, so
+// one 16-byte read feeds four v_mfma_f32_32x32x2_f32).  Wave w owns codes [32w, 32w+32) of the tile x all 64 rows.
+// ---------------------------------------------------------------------------------------------------------------
+#define VF_BX 64
+#define VF_BC 128
+#define VF_BK 32
+#define VF_EBYTES (VF_BC * VF_BK * 4)   // 16 KiB
+#define VF_XBYTES (VF_BX * VF_BK * 4)   // 8 KiB
+#define VF_STAGE (VF_EBYTES + VF_XBYTES)
+
+// rows x 32 floats tile (128-byte rows), 16-byte chunk index XORed with (row & 7); piece = 8 rows = 1 KiB
+__device__ __forceinline__ void vf_glds(const float* g, long long ld, int rows, unsigned char* lds, int wave, int lane) {
+  const int npieces = rows >> 3;
+  for (int p = wave; p < npieces; p += 4) {
+    const int row = 8 * p + (lane >> 3), slot = lane & 7;
+    const int chunk = slot ^ (row & 7);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + (long long)row * ld + chunk * 4),
+                                     (__attribute__((address_space(3))) void*)(lds + p * 1024), 16, 0, 0);
+  }
+}
+__device__ __forceinline__ f4v vf_frag(const unsigned char* img, int row, int j, int h5) {
+  return *(const f4v*)(img + row * 128 + ((((2 * j + h5)) ^ (row & 7)) << 4));
+}
+
+__global__ __launch_bounds__(256, 3) void vq_argmin_fast_k(const float* x, const float* e, const float* sx, const float* se,
+                                                           int64_t* indices, float* best_out, int K, int D) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ float cand_v[4][VF_BX];
+  __shared__ int cand_i[4][VF_BX];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h5 = lane >> 5, r = lane & 31;
+  const long long m0 = (long long)blockIdx.x * VF_BX;
+  const float sx0 = sx[m0 + r], sx1 = sx[m0 + 32 + r];
+  float best0 = INFINITY, best1 = INFINITY;
+  int bi0 = 0x7fffffff, bi1 = 0x7fffffff;
+  const int nks = D / VF_BK, nct = K / VF_BC;
+  const int nstage = nks * nct;
+
+  // stage s = (code tile s / nks, depth block s % nks)
+  vf_glds(e, D, VF_BC, smem, wave, lane);
+  vf_glds(x + m0 * D, D, VF_BX, smem + VF_EBYTES, wave, lane);
+  f16v acc0 = {0}, acc1 = {0};
+  for (int s = 0; s < nstage; s++) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const unsigned char* eimg = smem + (s & 1) * VF_STAGE;
+    const unsigned char* ximg = eimg + VF_EBYTES;
+    if (s + 1 < nstage) {
+      const int ct = (s + 1) / nks, kb = (s + 1) % nks;
+      unsigned char* d = smem + ((s + 1) & 1) * VF_STAGE;
+      vf_glds(e + (long long)ct * VF_BC * D + kb * VF_BK, D, VF_BC, d, wave, lane);
+      vf_glds(x + m0 * D + kb * VF_BK, D, VF_BX, d + VF_EBYTES, wave, lane);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const f4v ef = vf_frag(eimg, wave * 32 + r, j, h5);
+      const f4v x0 = vf_frag(ximg, r, j, h5);
+      const f4v x1 = vf_frag(ximg, 32 + r, j, h5);
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ef[q], x0[q], acc0, 0, 0, 0);  // D[code][row]
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ef[q], x1[q], acc1, 0, 0, 0);
+      }
+    }
+    if ((s % nks) == nks - 1) {  // a 128-code tile is complete: fold it into the running argmin, restart the sums
+      const int c0 = (s / nks) * VF_BC + wave * 32;
+#pragma unroll
+      for (int rr = 0; rr < 16; rr++) {
+        const int code = c0 + (rr & 3) + 8 * (rr >> 2) + 4 * h5;
+        const float sec = se[code];
+        const float d0 = (sx0 + sec) - 2.0f * acc0[rr];
+        const float d1 = (sx1 + sec) - 2.0f * acc1[rr];
+        if (d0 < best0) { best0 = d0; bi0 = code; }  // a lane visits its codes in increasing order
+        if (d1 < best1) { best1 = d1; bi1 = code; }
+      }
+      acc0 = (f16v){0};
+      acc1 = (f16v){0};
+    }
+  }
+  // lane halves hold interleaved code rows of the same feature row
+  {
+    float ov = __shfl_xor(best0, 32, 64); int oi = __shfl_xor(bi0, 32, 64);
+    if (ov < best0 || (ov == best0 && oi < bi0)) { best0 = ov; bi0 = oi; }
+    ov = __shfl_xor(best1, 32, 64); oi = __shfl_xor(bi1, 32, 64);
+    if (ov < best1 || (ov == best1 && oi < bi1)) { best1 = ov; bi1 = oi; }
+  }
+  if (lane < 32) { cand_v[wave][lane] = best0; cand_i[wave][lane] = bi0; cand_v[wave][32 + lane] = best1; cand_i[wave][32 + lane] = bi1; }
+  __syncthreads();
+  if (tid < VF_BX) {
+    float b = cand_v[0][tid];
+    int bi = cand_i[0][tid];
+#pragma unroll
+    for (int w = 1; w < 4; w++) {
+      const float ov = cand_v[w][tid];
+      const int oi = cand_i[w][tid];
+      if (ov < b || (ov == b && oi < bi)) { b = ov; bi = oi; }
+    }
+    indices[m0 + tid] = bi;
+    if (best_out) best_out[m0 + tid] = b;
+  }
+}
+
 __global__ __launch_bounds__(256) void vq_gather_k(const float* x, const float* e, const int64_t* idx, float* q, long long M, int D) {
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -112,8 +216,15 @@ extern "C" int pero_vq_argmin(const float* x, const float* codebook, int64_t* in
   float* se = work + M;
   hipLaunchKernelGGL(sqnorm_k, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, x, sx, (long long)M, (int)D);
   hipLaunchKernelGGL(sqnorm_k, dim3((unsigned)((K + 3) / 4)), dim3(256), 0, st, codebook, se, (long long)K, (int)D);
-  hipLaunchKernelGGL(vq_argmin_k, dim3((unsigned)((M + VQ_BX - 1) / VQ_BX)), dim3(256), 0, st, x, codebook, sx, se, indices, best_dist,
-                     (long long)M, (int)K, (int)D);
+  if (M % VF_BX == 0 && K % VF_BC == 0 && D % VF_BK == 0 && aligned16(x) && aligned16(codebook)) {
+    static bool attr = false;
+    if (!attr) { hipFuncSetAttribute((const void*)vq_argmin_fast_k, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * VF_STAGE); attr = true; }
+    hipLaunchKernelGGL(vq_argmin_fast_k, dim3((unsigned)(M / VF_BX)), dim3(256), 2 * VF_STAGE, st, x, codebook, sx, se, indices, best_dist,
+                       (int)K, (int)D);
+  } else {
+    hipLaunchKernelGGL(vq_argmin_k, dim3((unsigned)((M + VQ_BX - 1) / VQ_BX)), dim3(256), 0, st, x, codebook, sx, se, indices, best_dist,
+                       (long long)M, (int)K, (int)D);
+  }
   PERO_CHECK_LAUNCH("pero_vq_argmin");
   return PERO_OK;
 }

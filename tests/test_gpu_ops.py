@@ -421,6 +421,25 @@ def test_vq_argmin_codebook_8192(ops, golden):
     assert np.abs(best.cpu().numpy() - g["cb8192.best"]).max() < 1e-3
 
 
+def test_vq_argmin_fast_path_matches_generic_and_oracle(ops):
+    """LDS-DMA / b128-fragment kernel (M % 64, K % 128, D % 32 == 0) vs the f32 oracle; ties -> first index."""
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((192, 96)).astype(np.float32)
+    e = rng.standard_normal((384, 96)).astype(np.float32)
+    e[300] = e[7]
+    x[9] = e[7]
+    idx, best = ops.vq_argmin(dev(x), dev(e), want_dist=True)
+    ref, dist = O.vq_nearest(x, e)
+    b, s2 = O.margins(dist)
+    near = (s2 - b) < 1e-5 * np.abs(b) + 1e-6
+    assert np.array_equal(idx.cpu().numpy()[~near], ref[~near])
+    assert int(idx[9]) == 7
+    assert np.abs(best.cpu().numpy() - b).max() < 1e-3
+    # ragged sizes still take the generic kernel and agree on the common prefix
+    idx2 = ops.vq_argmin(dev(x[:100]), dev(e))
+    assert np.array_equal(idx2.cpu().numpy()[~near[:100]], ref[:100][~near[:100]])
+
+
 def test_gather_scatter(ops):
     g = torch.Generator().manual_seed(8)
     for dtype in (torch.float32, torch.bfloat16):
