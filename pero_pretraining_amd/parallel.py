@@ -63,9 +63,11 @@ class DataParallel:
         dp = DataParallel(model, optimizer); trainer = Trainer(..., data_parallel=dp)
     """
 
-    def __init__(self, model, optimizer, process_group=None, overlap=True):
+    def __init__(self, model, optimizer, process_group=None, overlap=True, layers_per_bucket=2):
         self.model, self.optimizer, self.group = model, optimizer, process_group
+        self.layers_per_bucket = max(1, int(layers_per_bucket))  # 2 layers = 25 MB f32 at d=512
         self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.active = dist.is_initialized()  # a 1-rank group still exercises the collective path
         self.overlap = overlap
         self._pending = []
         self._done = set()
@@ -80,7 +82,7 @@ class DataParallel:
 
     def broadcast_parameters(self):
         """Start every rank from rank 0's weights."""
-        if self.world_size == 1:
+        if not self.active:
             return
         for f in self.optimizer._flat:
             if f is not None:
@@ -95,17 +97,26 @@ class DataParallel:
             self._pending.append(dist.all_reduce(self.flat[g][a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def _stage_ready(self, stage):
-        if self.world_size == 1:
+        """Called by the backbone's backward when layer `stage` (or -1: the front end) has enqueued its last
+        gradient kernel.  Layers are reduced in groups of `layers_per_bucket` (fewer, larger collectives: xGMI ring
+        collectives are per-link bound and every launch costs a few microseconds of CU time)."""
+        if not self.active:
             return
         self._reduce("head")   # complete before the backbone's backward began
-        self._reduce(stage)
+        if stage == -1:
+            self._reduce(-1)
+            return
+        lpb = self.layers_per_bucket
+        if stage % lpb == 0:  # lowest layer of its group: the whole group [stage, stage + lpb) is complete
+            for s in range(stage, min(stage + lpb, self.num_layers)):
+                self._reduce(s)
 
     def begin_backward(self):
         self._pending, self._done = [], set()
 
     def finish_backward(self):
         """Reduce whatever has not been launched yet and make the compute stream wait for all of it."""
-        if self.world_size == 1:
+        if not self.active:
             return
         for stage in list(self.buckets.keys()):
             self._reduce(stage)
