@@ -53,26 +53,29 @@ __device__ __forceinline__ bf8v pack8(const f16v& a, int s) {
   return __builtin_bit_cast(bf8v, u);
 }
 
-__global__ __launch_bounds__(256, 2) void attn_fwd_k(const bf16raw* qkv, bf16raw* out, float* lse2, int S, int nh, float c) {
+// hpb = heads per workgroup: the (head, key tile) pairs of `hpb` heads of one line are walked as ONE stream, so the
+// LDS-DMA of the next head's first K / V tile and the global loads of its Q rows run under the current head's last
+// tile.  At S = 256 a (line, head, 128 queries) unit is only two key tiles: measured 439 TFLOP/s against 855 at S = 2048
+// with identical inner loops - the difference was the per-workgroup prologue / epilogue.
+__global__ __launch_bounds__(256, 2) void attn_fwd_k(const bf16raw* qkv, bf16raw* out, float* lse2, int S, int nh, int hpb, float c) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* kimg = smem;
   unsigned char* vimg = smem + AT_TILE_BYTES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h5 = lane >> 5, r = lane & 31;
-  const int nqb = S >> 7;
-  const int qb = blockIdx.x % nqb, lh = blockIdx.x / nqb;
-  const int line = lh / nh, head = lh % nh;
+  const int nqb = S >> 7, ngrp = nh / hpb;
+  const int qb = blockIdx.x % nqb, lg = blockIdx.x / nqb;
+  const int line = lg / ngrp, head0 = (lg % ngrp) * hpb;
   const long long d = (long long)nh * 128, ld = 3 * d;
-  const bf16raw* base = qkv + (long long)line * S * ld + head * 128;
-  const bf16raw* Kg = base + d;
-  const bf16raw* Vg = base + 2 * d;
+  const bf16raw* lbase = qkv + (long long)line * S * ld;  // + head * 128 : q ; + d : k ; + 2d : v
   const int q = qb * 128 + wave * 32 + r;  // this lane's query (both lane halves hold the same query)
+  const int nkt = S >> 7, units = hpb * nkt;
 
-  attn_glds_tile<false>(Kg, ld, kimg, wave, lane);
-  attn_glds_tile<true>(Vg, ld, vimg, wave, lane);
+  attn_glds_tile<false>(lbase + head0 * 128 + d, ld, kimg, wave, lane);
+  attn_glds_tile<true>(lbase + head0 * 128 + 2 * d, ld, vimg, wave, lane);
 
   bf8v qf[8];
   {
-    const bf16raw* qrow = base + (long long)q * ld + 8 * h5;
+    const bf16raw* qrow = lbase + head0 * 128 + (long long)q * ld + 8 * h5;
 #pragma unroll
     for (int ks = 0; ks < 8; ks++) qf[ks] = *(const bf8v*)(qrow + 16 * ks);
   }
@@ -80,11 +83,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_k(const bf16raw* qkv, bf16raw
 #pragma unroll
   for (int t = 0; t < 4; t++) o[t] = (f16v){0};
   float m = -INFINITY, l = 0.f;
-  const int nkt = S >> 7;
 
-  for (int kt = 0; kt < nkt; kt++) {
+  for (int u = 0; u < units; u++) {
+    const int head = head0 + u / nkt, kt = u % nkt;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();  // K(kt), V(kt) landed
+    __syncthreads();  // K(u), V(u) landed
     f16v s[4];
 #pragma unroll
     for (int t = 0; t < 4; t++) {
@@ -94,7 +97,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_k(const bf16raw* qkv, bf16raw
         s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(attn_k_frag(kimg, t * 32 + r, ks, h5), qf[ks], s[t], 0, 0, 0);
     }
     __syncthreads();  // every wave is done with the K image
-    if (kt + 1 < nkt) attn_glds_tile<false>(Kg + (long long)(kt + 1) * 128 * ld, ld, kimg, wave, lane);
+    if (u + 1 < units) {
+      const int nhd = head0 + (u + 1) / nkt, nkt_i = (u + 1) % nkt;
+      attn_glds_tile<false>(lbase + nhd * 128 + d + (long long)nkt_i * 128 * ld, ld, kimg, wave, lane);
+    }
 
     // ---- online softmax, all lane-local except one lane^32 exchange per reduction
     float mx = s[0][0];
@@ -104,7 +110,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_k(const bf16raw* qkv, bf16raw
       for (int e = 0; e < 16; e++) mx = fmaxf(mx, s[t][e]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float mn = fmaxf(m, mx);
-    const float alpha = __builtin_amdgcn_exp2f((m - mn) * c);  // exp2(-inf) = 0 on the first tile
+    const float alpha = __builtin_amdgcn_exp2f((m - mn) * c);  // exp2(-inf) = 0 on a head's first tile
     const float mc = mn * c;
     float ps = 0.f;
 #pragma unroll
@@ -134,25 +140,64 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_k(const bf16raw* qkv, bf16raw
           o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(attn_vT_frag(vimg, t * 32 + sub * 16, dt, lane), pf, o[dt], 0, 0, 0);
       }
     }
-    if (kt + 1 < nkt) {
+    if (kt == nkt - 1) {
+      // ---- head finished: O[q][d] = o[dt][reg] / l, staged through the (now free) V image so that HBM sees whole
+      // 256-byte rows in 16-byte lanes: the direct form (16 scattered 8-byte stores per lane) cost 23 % of the kernel
+      // at S = 256 - and vmcnt makes the next tile's DMA wait for them.  Image: 128 rows x 256 B, 8-byte granule index
+      // XORed with (row & 31): conflict-free ds_write_b64 (lanes = rows) and ds_read_b128 (lanes = chunks of a row).
       __syncthreads();  // every wave is done with the V image
-      attn_glds_tile<true>(Vg + (long long)(kt + 1) * 128 * ld, ld, vimg, wave, lane);
+      const float inv = 1.0f / l;
+      int qrow_l = wave * 32 + r, tid_l = tid;
+      asm volatile("" : "+v"(qrow_l), "+v"(tid_l));  // keep the 24 staging addresses out of the unit loop's live set
+#pragma unroll
+      for (int dt = 0; dt < 4; dt++)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; g4++) {
+          uint2 w;
+          w.x = pack2bf(o[dt][4 * g4 + 0] * inv, o[dt][4 * g4 + 1] * inv);
+          w.y = pack2bf(o[dt][4 * g4 + 2] * inv, o[dt][4 * g4 + 3] * inv);
+          const int g = dt * 8 + 2 * g4 + h5;  // granule of d = dt*32 + 8*g4 + 4*h5
+          *(uint2*)(vimg + qrow_l * 256 + ((g ^ (qrow_l & 31)) << 3)) = w;
+        }
+      if (h5 == 0) lse2[((long long)line * nh + head) * S + q] = m * c + __builtin_amdgcn_logf(l);  // base-2 LSE of c*scores
+      __syncthreads();
+      {
+        const int ch = tid_l & 15;
+#pragma unroll 2
+        for (int i = 0; i < 8; i++) {
+          const int row = (tid_l >> 4) + 16 * i;
+          const int x = row & 31;
+          uint4 v = *(const uint4*)(vimg + row * 256 + ((ch ^ (x >> 1)) << 4));
+          if (x & 1) { const unsigned t0 = v.x, t1 = v.y; v.x = v.z; v.y = v.w; v.z = t0; v.w = t1; }
+          *(uint4*)(out + ((long long)line * S + qb * 128 + row) * d + head * 128 + ch * 8) = v;
+        }
+      }
+      if (u + 1 < units) {  // next head: fresh statistics, its Q rows (the loads complete under the loop-top wait)
+#pragma unroll
+        for (int t = 0; t < 4; t++) o[t] = (f16v){0};
+        m = -INFINITY;
+        l = 0.f;
+        const bf16raw* qrow = lbase + (head + 1) * 128 + (long long)q * ld + 8 * h5;
+#pragma unroll
+        for (int ks = 0; ks < 8; ks++) qf[ks] = *(const bf8v*)(qrow + 16 * ks);
+      }
+    }
+    if (u + 1 < units) {
+      __syncthreads();  // every wave is done with the V image (and with the O staging reads)
+      const int nhd = head0 + (u + 1) / nkt, nkt_i = (u + 1) % nkt;
+      attn_glds_tile<true>(lbase + nhd * 128 + 2 * d + (long long)nkt_i * 128 * ld, ld, vimg, wave, lane);
     }
   }
+}
 
-  // ---- epilogue: O[q][d] = o[dt][reg] / l ; d = dt*32 + (reg&3) + 8*(reg>>2) + 4*h5 : 4 consecutive d per reg group
-  const float inv = 1.0f / l;
-  bf16raw* orow = out + ((long long)line * S + q) * d + head * 128;
-#pragma unroll
-  for (int dt = 0; dt < 4; dt++)
-#pragma unroll
-    for (int g4 = 0; g4 < 4; g4++) {
-      uint2 w;
-      w.x = pack2bf(o[dt][4 * g4 + 0] * inv, o[dt][4 * g4 + 1] * inv);
-      w.y = pack2bf(o[dt][4 * g4 + 2] * inv, o[dt][4 * g4 + 3] * inv);
-      *(uint2*)(orow + dt * 32 + 8 * g4 + 4 * h5) = w;
-    }
-  if (h5 == 0) lse2[(long long)lh * S + q] = m * c + __builtin_amdgcn_logf(l);  // base-2 log-sum-exp of c*scores
+// heads per workgroup: as many as keep >= 2 workgroups per CU busy
+static int attn_heads_per_block(long long N, long long S, long long nh) {
+  static int num_cus = 0;
+  if (!num_cus) { hipDeviceProp_t prop; int dev = 0; hipGetDevice(&dev); hipGetDeviceProperties(&prop, dev); num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256; }
+  int hpb = 1;
+  for (int cand = (int)nh; cand >= 1; cand--)
+    if (nh % cand == 0 && N * (S / 128) * (nh / cand) >= 2LL * num_cus) { hpb = cand; break; }
+  return hpb;
 }
 
 extern "C" int pero_attention_fwd(const void* qkv, void* out, float* lse, int64_t N, int64_t S, int64_t num_heads,
@@ -164,8 +209,9 @@ extern "C" int pero_attention_fwd(const void* qkv, void* out, float* lse, int64_
   static bool attr = false;
   if (!attr) { hipFuncSetAttribute((const void*)attn_fwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * AT_TILE_BYTES); attr = true; }
   const float c = (float)(1.4426950408889634 / sqrt((double)head_dim));
-  hipLaunchKernelGGL(attn_fwd_k, dim3((unsigned)(N * num_heads * (S / 128))), dim3(256), 2 * AT_TILE_BYTES, (hipStream_t)stream,
-                     (const bf16raw*)qkv, (bf16raw*)out, lse, (int)S, (int)num_heads, c);
+  const int hpb = attn_heads_per_block(N, S, num_heads);
+  hipLaunchKernelGGL(attn_fwd_k, dim3((unsigned)(N * (num_heads / hpb) * (S / 128))), dim3(256), 2 * AT_TILE_BYTES, (hipStream_t)stream,
+                     (const bf16raw*)qkv, (bf16raw*)out, lse, (int)S, (int)num_heads, hpb, c);
   PERO_CHECK_LAUNCH("pero_attention_fwd");
   return PERO_OK;
 }
