@@ -195,6 +195,17 @@ int pero_rownorm_bwd(const void* xn, const void* dxn, const float* inv, const fl
 int pero_ntxent_cols(const float* sim, float* line_loss, float* loss_out, void* dsim, int64_t lines, int64_t S, int dtype,
                      void* stream);
 
+/* ---- evaluation -------------------------------------------------------------
+ * replaces masked_pretraining/tester.py:72-113 (_update_errors / _topk / _calculate_errors: host numpy argmax and
+ * argsort over the full logit tensor).  For every row with mask == 1: gt = #{j : logit[j] > logit[label]},
+ * eq_lo / eq_hi = #{j : logit[j] == logit[label], j < label / j > label}.  counters (u64 [1 + nk], ACCUMULATED, caller
+ * zeroes them once per test()): [0] += rows with mask == 1 ("length"), [1 + i] += rows whose label is not in the top
+ * ks[i] (k == 1: argmax = first maximum; k > 1: stable-argsort order, see csrc/eval.hip).  ranks (int32 [rows][3],
+ * may be null): gt, eq_lo, eq_hi, or -1 where mask != 1.  ks is a DEVICE pointer (nk <= PERO_MAX_TOPK). */
+#define PERO_MAX_TOPK 8
+int pero_label_rank(const void* logits, int64_t ld, const int64_t* labels, const int64_t* mask, int64_t rows, int64_t V,
+                    const int32_t* ks, int32_t nk, uint64_t* counters, int32_t* ranks, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

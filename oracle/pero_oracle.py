@@ -320,6 +320,52 @@ def joint_model_forward(sd, images1_nchw, images2_nchw, masks, num_heads, loss="
 # --------------------------------------------------------------------------------------------
 # whole training step (used for trajectory parity and as the bench's CPU baseline "port")
 # --------------------------------------------------------------------------------------------
+# -------------------------------------------------------------------------------------------------
+# Evaluation
+# -------------------------------------------------------------------------------------------------
+def topk_error_counts(output, labels, mask, measured_errors=(1, 3, 10)):
+    """masked_pretraining/tester.py:72-113 (_update_errors, _topk, _calculate_errors) restated:
+    output (N, S, V) numpy, labels / mask (N, S).  Returns ({'errors_k': count}, length)."""
+    output, labels, mask = np.asarray(output), np.asarray(labels), np.asarray(mask)
+    masked_output = output[mask == 1]
+    masked_labels = labels[mask == 1]
+    counts = {}
+    for k in measured_errors:
+        if k == 1:
+            pred = np.argmax(masked_output, axis=1)                        # tester.py:86 (first maximum)
+            counts[f"errors_{k}"] = int(np.sum(pred != masked_labels))
+        else:
+            top = np.argsort(masked_output, axis=1, kind="stable")[:, -k:]  # tester.py:94-96 (ties: see eval.hip)
+            counts[f"errors_{k}"] = int(sum(r not in h for h, r in zip(top, masked_labels)))
+    return counts, int(masked_labels.shape[0])
+
+
+def label_ranks(output2d, labels, mask):
+    """(rows, 3) int32: #{logit > x}, #{logit == x, j < label}, #{logit == x, j > label} per row with mask == 1
+    (x = logit[label]); -1 elsewhere.  The quantity pero_label_rank returns."""
+    output2d = np.asarray(output2d, dtype=np.float32)
+    rows, V = output2d.shape
+    out = np.full((rows, 3), -1, dtype=np.int32)
+    j = np.arange(V)
+    for r in range(rows):
+        if mask[r] != 1:
+            continue
+        lab = int(labels[r])
+        if not 0 <= lab < V:
+            out[r] = (V, 0, 0)
+            continue
+        x = output2d[r, lab]
+        eq = output2d[r] == x
+        out[r] = (int(np.sum(output2d[r] > x)), int(np.sum(eq & (j < lab))), int(np.sum(eq & (j > lab))))
+    return out
+
+
+def errors_from_ranks(ranks, measured_errors=(1, 3, 10)):
+    act = ranks[:, 0] >= 0
+    gt, lo, hi = ranks[act, 0], ranks[act, 1], ranks[act, 2]
+    return {f"errors_{k}": int(np.sum((gt + lo) >= 1) if k == 1 else np.sum((gt + hi) >= k)) for k in measured_errors}, int(act.sum())
+
+
 class MaskedStepOracle:
     """Plain-tensor restatement of Trainer.train_step (masked_pretraining/trainer.py:53-68):
     prepare_batch -> forward -> backward (autograd over the restated arithmetic) -> Adam."""

@@ -308,3 +308,20 @@ def ntxent_cols(sim, want_grad_dtype=None):
     call("pero_ntxent_cols", ptr(sim), ptr(line_loss), ptr(loss), ptr(dsim), lines, S,
          dt(want_grad_dtype) if want_grad_dtype is not None else PERO_F32, stream())
     return loss, line_loss, dsim
+
+
+MAX_TOPK = 8
+
+
+def label_rank(logits, labels, mask, ks=None, counters=None, want_ranks=False):
+    """Rank of each masked row's label inside its logit row + accumulated top-k error counters
+    (masked_pretraining/tester.py:72-113 on the device).  logits (rows, V) f32/bf16 (row pitch = stride(0));
+    labels, mask (rows,) int64; ks: int32 device tensor of measured errors; counters: int64 device tensor
+    [1 + len(ks)] that is ACCUMULATED into.  Returns (counters, ranks or None)."""
+    rows, V = logits.shape
+    assert logits.stride(1) == 1 and labels.numel() == rows and mask.numel() == rows
+    nk = 0 if ks is None else int(ks.numel())
+    ranks = torch.empty((rows, 3), device=logits.device, dtype=torch.int32) if want_ranks else None
+    call("pero_label_rank", ptr(logits), logits.stride(0), ptr(labels), ptr(mask), rows, V, ptr(ks), nk, ptr(counters),
+         ptr(ranks), dt(logits.dtype), stream())
+    return counters, ranks

@@ -1,0 +1,37 @@
+"""CPU tests of the SURVEY.md section 8(f) "next" rows: the oracle's restatements against what the reference itself
+produced (tests/golden g12-g15, oracle/make_golden_next.py) and the host-side logic of the product package."""
+import os
+
+import numpy as np
+import torch
+
+from oracle import pero_oracle as O
+
+
+def test_oracle_topk_errors_match_reference_tester(golden):
+    g = golden("g12_tester.npz")
+    tot = {"errors_1": 0, "errors_3": 0, "errors_10": 0}
+    length = 0
+    rk = {"errors_1": 0, "errors_3": 0, "errors_10": 0}
+    for i in range(int(g["n_batches"])):
+        out, lab, msk = g[f"b{i}.output"], g[f"b{i}.labels"], g[f"b{i}.mask"]
+        counts, n = O.topk_error_counts(out, lab, msk, (1, 3, 10))
+        ranks = O.label_ranks(out.reshape(-1, out.shape[-1]), lab.reshape(-1), msk.reshape(-1))
+        c2, n2 = O.errors_from_ranks(ranks, (1, 3, 10))
+        assert n == n2 and counts == c2   # the rank formulation (what the kernel computes) == numpy argmax / argsort
+        for k in tot:
+            tot[k] += counts[k]; rk[k] += c2[k]
+        length += n
+    for k in tot:
+        assert tot[k] / length == float(g[k]), (k, tot[k], length, float(g[k]))
+
+
+def test_oracle_rank_tie_rules():
+    out = np.array([[1.0, 3.0, 3.0, 2.0, 3.0], [0.0, 0.0, 0.0, 0.0, 0.0]], dtype=np.float32)
+    labels = np.array([2, 4]); mask = np.array([1, 1])
+    r = O.label_ranks(out, labels, mask)
+    assert r.tolist() == [[0, 1, 1], [0, 4, 0]]
+    # argmax picks index 1 (first max) -> label 2 is an error at k=1; stable top-2 = indices {2, 4} -> no error at k=2
+    c, n = O.topk_error_counts(out[None], labels[None], mask[None], (1, 2))
+    assert c == {"errors_1": 2, "errors_2": 0} and n == 2
+    assert O.errors_from_ranks(r, (1, 2))[0] == c
