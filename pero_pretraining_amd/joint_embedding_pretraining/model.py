@@ -80,4 +80,5 @@ class JointEmbeddingTransformerEncoder(torch.nn.Module):
         torch.save(self.state_dict(), path)
 
     def load(self, path):
-        self.load_state_dict(torch.load(path))
+        device = next(self.parameters()).device
+        self.load_state_dict(torch.load(path, map_location=device, weights_only=True))

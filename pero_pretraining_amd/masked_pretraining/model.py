@@ -131,4 +131,7 @@ class MaskedTransformerEncoder(torch.nn.Module):
         torch.save(self.state_dict(), path)
 
     def load(self, path):
-        self.load_state_dict(torch.load(path))
+        """masked_pretraining/model.py:68-69; the file is a plain state_dict (reference format) and is read with the
+        loader that executes nothing from it."""
+        device = next(self.parameters()).device
+        self.load_state_dict(torch.load(path, map_location=device, weights_only=True))

@@ -11,10 +11,13 @@ from . import lowp, ops
 
 
 class FusedAdam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0):
-        if weight_decay != 0:
-            raise ValueError("FusedAdam: weight_decay is not implemented (the reference uses 0)")
-        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False, maximize=False):
+        if weight_decay != 0 or amsgrad or maximize:
+            raise ValueError("FusedAdam: weight_decay / amsgrad / maximize are not implemented (the reference uses none)")
+        # the remaining keys are torch.optim.Adam's group defaults, carried so that state_dict()s are interchangeable
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False, maximize=False,
+                                      foreach=None, capturable=False, differentiable=False, fused=None,
+                                      decoupled_weight_decay=False))
         self._flat = []  # per group: dict(p, g, m, v, lp, step)
         self.grad_scale = 1.0
         self._flatten()
@@ -76,6 +79,56 @@ class FusedAdam(torch.optim.Optimizer):
             for p, o in zip(f["params"], f["offsets"]):
                 if p.grad is None or p.grad.data_ptr() != f["g"].data_ptr() + 4 * o:
                     p.grad = f["g"][o:o + p.numel()].view(p.shape)
+
+    # ---- checkpointing: the layout of torch.optim.Adam's state_dict (per-parameter 'step', 'exp_avg', 'exp_avg_sq'),
+    # so optimizer state moves between this class and torch.optim.Adam (the reference's optimizer,
+    # masked_pretraining/train.py:146) in both directions.  The reference itself never saves it.
+    def state_dict(self):
+        state, groups, idx = {}, [], 0
+        for group, f in zip(self.param_groups, self._flat):
+            offs = {id(p): o for p, o in zip(f["params"], f["offsets"])} if f is not None else {}
+            ids = []
+            for p in group["params"]:
+                if id(p) in offs and f["step"] > 0:
+                    o, n = offs[id(p)], p.numel()
+                    state[idx] = {"step": torch.tensor(float(f["step"])),
+                                  "exp_avg": f["m"][o:o + n].view(p.shape).clone(),
+                                  "exp_avg_sq": f["v"][o:o + n].view(p.shape).clone()}
+                ids.append(idx)
+                idx += 1
+            g = {k: v for k, v in group.items() if k != "params"}
+            g["params"] = ids
+            groups.append(g)
+        return {"state": state, "param_groups": groups}
+
+    def load_state_dict(self, state_dict):
+        groups = state_dict["param_groups"]
+        if len(groups) != len(self.param_groups):
+            raise ValueError("loaded state dict has a different number of parameter groups")
+        for group, saved, f in zip(self.param_groups, groups, self._flat):
+            if len(saved["params"]) != len(group["params"]):
+                raise ValueError("loaded state dict contains a parameter group that doesn't match the size of optimizer's group")
+            if saved.get("weight_decay", 0) != 0 or saved.get("amsgrad", False) or saved.get("maximize", False):
+                raise ValueError("FusedAdam: the loaded group uses weight_decay / amsgrad / maximize")
+            for k, v in saved.items():
+                if k != "params":
+                    group[k] = v
+            if f is None:
+                continue
+            offs = {id(p): o for p, o in zip(f["params"], f["offsets"])}
+            f["m"].zero_(); f["v"].zero_()
+            steps = set()
+            for p, idx in zip(group["params"], saved["params"]):
+                st = state_dict["state"].get(idx)
+                if st is None or id(p) not in offs:
+                    continue
+                o, n = offs[id(p)], p.numel()
+                f["m"][o:o + n].copy_(st["exp_avg"].reshape(-1))
+                f["v"][o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
+                steps.add(int(float(st["step"])))
+            if len(steps) > 1:
+                raise ValueError(f"FusedAdam keeps one step counter per group, got {sorted(steps)}")
+            f["step"] = steps.pop() if steps else 0
 
     @torch.no_grad()
     def step(self, closure=None):

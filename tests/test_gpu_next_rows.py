@@ -97,3 +97,110 @@ def test_masked_tester_bf16_and_joint_tester(golden):
              "shift_masks": j["shift_masks1"], "shift_masks2": j["shift_masks2"]}
     out = JTester(JBop(torch.device("cuda")), jmodel, [batch, batch]).test()
     assert abs(float(out["loss"]) - float(j["loss"])) < 1e-4 * abs(float(j["loss"]))
+
+
+# ---- (f2) checkpoints / resume ------------------------------------------------------------------------------------
+BB32 = {"type": "vit", "num_blocks": 2, "model_dim": 32, "num_heads": 4, "feedforward_dim": 64}
+HD32 = {"type": "linear", "in_features": 32, "out_features": 24}
+
+
+def test_reference_checkpoint_round_trip(golden, tmp_path):
+    from pero_pretraining_amd.common import helpers as H
+    from pero_pretraining_amd.masked_pretraining.train import init_model
+    g = golden("g13_checkpoint.npz")
+    ref_ckpt = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g13_reference_checkpoint.pth")
+    model = init_model(torch.device("cuda"), dict(BB32), dict(HD32), path=ref_ckpt).eval()   # a file the REFERENCE wrote
+    sd = model.state_dict()
+    assert list(sd.keys()) == list(g["keys"])
+    assert [str(tuple(v.shape)) for v in sd.values()] == list(g["shapes"])
+    assert [str(v.dtype) for v in sd.values()] == list(g["dtypes"])
+    res = model(torch.from_numpy(g["images"]).cuda(), torch.from_numpy(g["labels"]).cuda(), g["mask"].copy())
+    assert np.abs(res["output"].detach().float().cpu().numpy() - g["output"]).max() < 1e-4
+    assert abs(float(res["loss"]) - float(g["loss"])) < 1e-4 * float(g["loss"])
+    # our save() writes the same format: a plain tensor state_dict with the reference's keys, bit-identical values
+    mine = str(tmp_path / os.path.basename(H.get_checkpoint_path("x", 7)))
+    model.save(mine)
+    a = torch.load(ref_ckpt, map_location="cpu", weights_only=True)
+    b = torch.load(mine, map_location="cpu", weights_only=True)
+    assert list(a.keys()) == list(b.keys()) and all(torch.equal(a[k], b[k]) for k in a)
+    assert H.get_checkpoint_path("ckpts", 7) == str(g["checkpoint_path_7"])
+    assert H.get_visualization_path("vis", 7, "trn") == str(g["visualization_path_7"])
+
+
+def _grads_like(params, seed):
+    gen = torch.Generator(device="cuda").manual_seed(seed)
+    return [torch.randn(p.shape, device="cuda", generator=gen) * 0.1 for p in params]
+
+
+def test_fused_adam_state_dict_interchanges_with_torch_adam():
+    """Optimizer state written by FusedAdam continues correctly inside torch.optim.Adam (the reference's optimizer) and back."""
+    from pero_pretraining_amd.optim import FusedAdam
+    torch.manual_seed(0)
+    shapes = [(24, 32), (24,), (7, 5, 3), (1,)]
+    mine = [torch.nn.Parameter(torch.randn(s, device="cuda")) for s in shapes]
+    theirs = [torch.nn.Parameter(p.detach().clone()) for p in mine]
+    fa = FusedAdam(mine, lr=3e-3)
+    ta = torch.optim.Adam(theirs, lr=3e-3)
+    assert fa.state_dict()["state"] == {}
+    for step in range(2):  # two steps with FusedAdam only
+        fa.zero_grad()
+        for p, g in zip(mine, _grads_like(mine, step)):
+            p.grad.copy_(g)
+        fa.step()
+    for p, q in zip(mine, theirs):
+        q.data.copy_(p.data)
+    ta.load_state_dict(fa.state_dict())          # FusedAdam -> torch.optim.Adam
+    for step in range(2, 4):
+        gs = _grads_like(mine, step)
+        fa.zero_grad()
+        for p, q, g in zip(mine, theirs, gs):
+            p.grad.copy_(g); q.grad = g.clone()
+        fa.step(); ta.step()
+    for p, q in zip(mine, theirs):
+        assert (p - q).abs().max() < 2e-6
+    fresh = [torch.nn.Parameter(q.detach().clone()) for q in theirs]
+    fb = FusedAdam(fresh, lr=1.0)
+    fb.load_state_dict(ta.state_dict())          # torch.optim.Adam -> FusedAdam
+    assert fb.param_groups[0]["lr"] == 3e-3 and fb._flat[0]["step"] == 4
+    gs = _grads_like(mine, 9)
+    fb.zero_grad()
+    for p, q, g in zip(fresh, theirs, gs):
+        p.grad.copy_(g); q.grad = g.clone()
+    fb.step(); ta.step()
+    for p, q in zip(fresh, theirs):
+        assert (p - q).abs().max() < 2e-6
+
+
+def test_resume_continues_the_trajectory(golden, tmp_path):
+    from pero_pretraining_amd.masked_pretraining import train as T
+    g = golden("g12_tester.npz")
+    rng = np.random.default_rng(5)
+    batches = [{"images": rng.integers(0, 256, (2, 40, 64, 3), dtype=np.uint8), "labels": rng.integers(0, 24, (2, 8))}
+               for _ in range(6)]
+    tst = [{"images": g["b2.images"], "labels": g["b2.labels"]}]
+    ckpts = str(tmp_path)
+
+    def make(seed, data):
+        torch.manual_seed(seed)
+        model = T.init_model(torch.device("cuda"), dict(BB32), dict(HD32))
+        bop = T.init_batch_operator(torch.device("cuda"), 0.4)
+        trn_t, tst_t = T.init_testers(bop, model, tst, tst)
+        return T.init_training(bop, model, data, trn_t, tst_t, 2e-3, 4, ckpts), model
+
+    np.random.seed(3); torch.manual_seed(3)
+    trainer, model = make(1, batches)
+    trainer.train(end_iteration=5, start_iteration=0, view_step=3)   # view step (checkpoint + tests) after iteration 3
+    want = {k: v.clone() for k, v in model.state_dict().items()}
+    assert os.path.exists(T.get_checkpoint_path(ckpts, 3)) and os.path.exists(T.get_training_state_path(ckpts, 3))
+
+    np.random.seed(1234); torch.manual_seed(1234)                      # a different process: other RNG state, other init
+    trainer2, model2 = make(2, batches[4:])
+    start = T.resume(trainer2, ckpts, 3)
+    assert start == 4 and trainer2.optimizer._flat[0]["step"] == 4
+    trainer2.train(end_iteration=5, start_iteration=start, view_step=1000)
+    for k, v in model2.state_dict().items():                            # split-K f32 atomics: not bit-reproducible
+        assert (v - want[k]).abs().max() <= 1e-5 * max(1.0, float(want[k].abs().max())), k
+
+    trainer3, model3 = make(2, batches[3:])                             # reference behaviour: weights only, iteration 3 repeated
+    os.remove(T.get_training_state_path(ckpts, 3))
+    assert T.resume(trainer3, ckpts, 3) == 3 and trainer3.optimizer._flat[0]["step"] == 0

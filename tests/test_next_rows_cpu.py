@@ -35,3 +35,26 @@ def test_oracle_rank_tie_rules():
     c, n = O.topk_error_counts(out[None], labels[None], mask[None], (1, 2))
     assert c == {"errors_1": 2, "errors_2": 0} and n == 2
     assert O.errors_from_ranks(r, (1, 2))[0] == c
+
+
+def test_reference_checkpoint_fixture_is_a_plain_state_dict(golden):
+    """The file the reference's `model.save()` wrote loads with the non-executing loader and lists the documented keys."""
+    g = golden("g13_checkpoint.npz")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g13_reference_checkpoint.pth")
+    sd = torch.load(path, map_location="cpu", weights_only=True)
+    assert list(sd.keys()) == list(g["keys"])
+    assert [str(tuple(v.shape)) for v in sd.values()] == list(g["shapes"])
+    assert "backbone.conv_layer.weight" in sd and "head.linear.bias" in sd
+    assert not any(k.endswith(".pe") or "mask_pattern" in k for k in sd)   # non-persistent buffers (SURVEY 8b)
+    # oracle forward on those weights reproduces the reference output stored beside the checkpoint
+    x = O.prepare_images(torch.from_numpy(g["images"]))
+    out, loss = O.masked_model_forward(sd, x, torch.from_numpy(g["labels"]), torch.from_numpy(g["mask"]), num_heads=4)
+    assert np.abs(out.numpy() - g["output"]).max() < 1e-4
+    assert abs(float(loss) - float(g["loss"])) < 1e-5 * float(g["loss"])
+
+
+def test_helper_paths_match_reference(golden):
+    from pero_pretraining_amd.common import helpers as H
+    g = golden("g13_checkpoint.npz")
+    assert H.get_checkpoint_path("ckpts", 7) == str(g["checkpoint_path_7"])
+    assert H.get_visualization_path("vis", 7, "trn") == str(g["visualization_path_7"])
