@@ -206,6 +206,20 @@ int pero_ntxent_cols(const float* sim, float* line_loss, float* loss_out, void* 
 int pero_label_rank(const void* logits, int64_t ld, const int64_t* labels, const int64_t* mask, int64_t rows, int64_t V,
                     const int32_t* ks, int32_t nk, uint64_t* counters, int32_t* ranks, int dtype, void* stream);
 
+/* ---- batch collation -------------------------------------------------------------
+ * replaces common/dataloader.py:68-155 (BatchCreator.stack_images: host numpy zero-fill + slice copies + mask loops).
+ * packed: the ragged uint8 lines back to back, line b = (H, widths[b], C) row-major at byte offsets[b]; the buffer must
+ * be readable 8 bytes past its end.  out (B, H, Wt, C) u8, every byte written: line b's pixels at columns
+ * [left_px[b], left_px[b] + widths[b]), zero elsewhere.  Wt*C must be a multiple of 16 (Wt % 32 == 0 in the reference). */
+int pero_stack_lines(const void* packed, const int64_t* offsets, const int32_t* widths, const int32_t* left_px, void* out,
+                     int64_t B, int64_t H, int64_t Wt, int64_t C, void* stream);
+/* image masks (B, S) u8 (dataloader.py:92-96), shifts (B) i32 = crop_shifts + left1 - left2 (:126; left* in label
+ * positions), three-valued shift masks (:124-138).  Second-view outputs may all be null (unpaired batch);
+ * crop_shifts may be null (= 0). */
+int pero_line_masks(const int32_t* widths1, const int32_t* widths2, const int32_t* left1, const int32_t* left2,
+                    const int32_t* crop_shifts, uint8_t* image_masks1, uint8_t* image_masks2, uint8_t* shift_masks1,
+                    uint8_t* shift_masks2, int32_t* shifts, int64_t B, int64_t S, int64_t subsampling, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

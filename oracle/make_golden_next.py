@@ -135,10 +135,10 @@ def main():
     fix["lines_flat"] = np.concatenate([l.reshape(-1) for l in lines]); fix["lines2_flat"] = np.concatenate([l.reshape(-1) for l in lines2])
     fix["labels_flat"] = np.concatenate([np.asarray(l, dtype=np.int64) for l in line_labels])
     for name, kwargs, paired, seed in (("pad", {}, True, 5), ("pad_same", {"same_left_paddings": True}, True, 6),
-                                      ("single", {}, False, 7)):
+                                      ("single", {}, False, 7), ("crop", {"crop_width": 256, "crop_step": 8}, True, 8)):
         bc = R_dl.BatchCreator(**kwargs)
-        data = [{"image": a, "image2": (b if paired else None), "labels": l, "image_id": f"id{i}"}
-                for i, (a, b, l) in enumerate(zip(lines, lines2, line_labels))]
+        data = [{"image": a, "image2": (b if paired else None), "labels": (None if name == "crop" else l), "image_id": f"id{i}"}
+                for i, (a, b, l) in enumerate(zip(lines, lines2, line_labels))]   # crop mode: unlabeled (joint training)
         np.random.seed(seed)
         batch = bc.create_batch(data)
         fix[f"{name}.seed"] = np.int64(seed)
@@ -146,6 +146,9 @@ def main():
             if batch[k] is not None:
                 fix[f"{name}.{k}"] = np.asarray(batch[k])
         fix[f"{name}.ids"] = np.array(batch["ids"])
+        if batch["original_images"] is not None:
+            fix[f"{name}.original_images_shape"] = np.array(batch["original_images"].shape)
+            fix[f"{name}.original_images_sum"] = np.int64(batch["original_images"].astype(np.int64).sum())
     np.savez_compressed(os.path.join(out, "g15_batch_creator.npz"), **fix)
     print({f: os.path.getsize(os.path.join(out, f)) for f in sorted(os.listdir(out)) if f.startswith(("g12", "g13", "g14", "g15"))})
 

@@ -366,6 +366,45 @@ def errors_from_ranks(ranks, measured_errors=(1, 3, 10)):
     return {f"errors_{k}": int(np.sum((gt + lo) >= 1) if k == 1 else np.sum((gt + hi) >= k)) for k in measured_errors}, int(act.sum())
 
 
+# -------------------------------------------------------------------------------------------------
+# Batch collation
+# -------------------------------------------------------------------------------------------------
+def padded_width(max_width, padding_coefficient=32):
+    """common/dataloader.py:197-198."""
+    return int(np.ceil(max_width / padding_coefficient) * padding_coefficient) + padding_coefficient
+
+
+def collate_view(lines, left_paddings, target_width, sub=8):
+    """common/dataloader.py:80-100 for GIVEN left paddings (label positions): padded uint8 batch + image mask."""
+    h, c = lines[0].shape[0], lines[0].shape[2]
+    images = np.zeros((len(lines), h, target_width, c), dtype=np.uint8)
+    masks = np.ones((len(lines), target_width // sub), dtype=np.uint8)
+    for img, m, line, lp in zip(images, masks, lines, left_paddings):
+        img[:, lp * sub:lp * sub + line.shape[1]] = line
+        m[:lp] = 0
+        m[lp + int(np.ceil(line.shape[1] / sub)):] = 0
+    return images, masks
+
+
+def shift_masks(shifts, image_masks1, image_masks2):
+    """common/dataloader.py:128-138: three-valued masks (1 = shared position, 2 = shared but padding in that view)."""
+    sm1 = np.zeros_like(image_masks1)
+    for row, shift in zip(sm1, shifts):
+        if shift < 0:
+            row[:shift] = 1
+        else:
+            row[shift:] = 1
+    sm2 = np.copy(sm1[:, ::-1])
+    sm1[np.bitwise_and(sm1 == 1, image_masks1 == 0)] = 2
+    sm2[np.bitwise_and(sm2 == 1, image_masks2 == 0)] = 2
+    return sm1, sm2
+
+
+def draw_left_paddings(lines, target_width, sub=8):
+    """The reference's RNG consumption for one view (common/dataloader.py:86-89), from the global numpy stream."""
+    return [0 if l.shape[1] == target_width else np.random.randint(0, target_width - l.shape[1]) // sub for l in lines]
+
+
 class MaskedStepOracle:
     """Plain-tensor restatement of Trainer.train_step (masked_pretraining/trainer.py:53-68):
     prepare_batch -> forward -> backward (autograd over the restated arithmetic) -> Adam."""

@@ -15,13 +15,13 @@ class BatchOperator:
                 self._prepare_batch_masks(batch, "shift_masks"), self._prepare_batch_masks(batch, "shift_masks2"))
 
     def _prepare_batch_images(self, batch, key="images"):
-        images = torch.from_numpy(batch[key]).to(self.device, non_blocking=True)
+        images = torch.as_tensor(batch[key]).to(self.device, non_blocking=True)  # numpy (reference) or device tensor (GPU BatchCreator)
         if self.float_images:
             images = images.float().permute(0, 3, 1, 2) / 255.0
         return images
 
     def _prepare_batch_masks(self, batch, key="image_masks"):
-        return torch.from_numpy(batch[key]).to(self.device, non_blocking=True)
+        return torch.as_tensor(batch[key]).to(self.device, non_blocking=True)
 
     @staticmethod
     def batch_size(batch):

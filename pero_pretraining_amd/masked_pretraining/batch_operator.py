@@ -17,13 +17,13 @@ class BatchOperator:
         return self._prepare_batch_images(batch), self._prepare_batch_labels(batch), self._create_mask(batch)
 
     def _prepare_batch_images(self, batch):
-        images = torch.from_numpy(batch["images"]).to(self.device, non_blocking=True)
+        images = torch.as_tensor(batch["images"]).to(self.device, non_blocking=True)  # numpy (reference) or device tensor (GPU BatchCreator)
         if self.float_images:  # reference layout; only used when a caller needs the float tensor itself
             images = images.float().permute(0, 3, 1, 2) / 255.0
         return images
 
     def _prepare_batch_labels(self, batch):
-        return torch.from_numpy(batch["labels"]).to(self.device, non_blocking=True).long()
+        return torch.as_tensor(batch["labels"]).to(self.device, non_blocking=True).long()
 
     def _create_mask(self, batch):
         # host numpy RNG, exactly as masked_pretraining/batch_operator.py:27-32 (returns a numpy int array)

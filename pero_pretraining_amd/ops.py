@@ -325,3 +325,27 @@ def label_rank(logits, labels, mask, ks=None, counters=None, want_ranks=False):
     call("pero_label_rank", ptr(logits), logits.stride(0), ptr(labels), ptr(mask), rows, V, ptr(ks), nk, ptr(counters),
          ptr(ranks), dt(logits.dtype), stream())
     return counters, ranks
+
+
+def stack_lines(packed, offsets, widths, left_px, B, H, Wt, C):
+    """Ragged uint8 lines (device, back to back, readable 8 bytes past the end) -> zero-padded (B, H, Wt, C) uint8 batch
+    (common/dataloader.py:80-100).  offsets int64, widths / left_px int32 device tensors."""
+    out = torch.empty((B, H, Wt, C), device=packed.device, dtype=torch.uint8)
+    call("pero_stack_lines", ptr(packed), ptr(offsets), ptr(widths), ptr(left_px), ptr(out), B, H, Wt, C, stream())
+    return out
+
+
+def line_masks(widths1, left1, S, subsampling, widths2=None, left2=None, crop_shifts=None):
+    """Image masks, shifts and three-valued shift masks (common/dataloader.py:92-96, 124-138) from the per-line widths (px)
+    and left paddings (label positions): int32 device tensors.  Returns (im1, im2, sm1, sm2, shifts); the last four are
+    None for an unpaired batch."""
+    B = widths1.numel()
+    dev = widths1.device
+    im1 = torch.empty((B, S), device=dev, dtype=torch.uint8)
+    im2 = sm1 = sm2 = shifts = None
+    if widths2 is not None:
+        im2, sm1, sm2 = (torch.empty((B, S), device=dev, dtype=torch.uint8) for _ in range(3))
+        shifts = torch.empty(B, device=dev, dtype=torch.int32)
+    call("pero_line_masks", ptr(widths1), ptr(widths2), ptr(left1), ptr(left2), ptr(crop_shifts), ptr(im1), ptr(im2), ptr(sm1),
+         ptr(sm2), ptr(shifts), B, S, subsampling, stream())
+    return im1, im2, sm1, sm2, shifts

@@ -204,3 +204,81 @@ def test_resume_continues_the_trajectory(golden, tmp_path):
     trainer3, model3 = make(2, batches[3:])                             # reference behaviour: weights only, iteration 3 repeated
     os.remove(T.get_training_state_path(ckpts, 3))
     assert T.resume(trainer3, ckpts, 3) == 3 and trainer3.optimizer._flat[0]["step"] == 0
+
+
+# ---- (f4) batch collation on the device ------------------------------------------------------------------------------
+def _g15_lines(g):
+    widths = [int(w) for w in g["widths"]]
+    out, out2, labels = [], [], []
+    p = q = 0
+    for w in widths:
+        n = 10 * w * 3
+        out.append(g["lines_flat"][p:p + n].reshape(10, w, 3)); out2.append(g["lines2_flat"][p:p + n].reshape(10, w, 3))
+        p += n
+        t = int(np.ceil(w / 8))
+        labels.append(g["labels_flat"][q:q + t].tolist()); q += t
+    return out, out2, labels
+
+
+@pytest.mark.parametrize("mode", ["pad", "pad_same", "single", "crop"])
+def test_batch_creator_bit_exact_vs_reference(golden, mode):
+    from pero_pretraining_amd.common.dataloader import BatchCreator
+    g = golden("g15_batch_creator.npz")
+    lines, lines2, labels = _g15_lines(g)
+    kwargs = {"pad": {}, "pad_same": {"same_left_paddings": True}, "single": {}, "crop": {"crop_width": 256, "crop_step": 8}}[mode]
+    data = [{"image": a, "image2": (b if mode != "single" else None), "labels": (None if mode == "crop" else l), "image_id": f"id{i}"}
+            for i, (a, b, l) in enumerate(zip(lines, lines2, labels))]
+    np.random.seed(int(g[f"{mode}.seed"]))
+    batch = BatchCreator(**kwargs).create_batch(data)
+    for k in ("images", "images2", "image_masks", "image_masks2", "shift_masks", "shift_masks2"):
+        if f"{mode}.{k}" in g.files:
+            assert batch[k].is_cuda and batch[k].dtype == torch.uint8
+            assert np.array_equal(batch[k].cpu().numpy(), g[f"{mode}.{k}"]), k
+        else:
+            assert batch[k] is None, k
+    if f"{mode}.shifts" in g.files:
+        assert list(batch["shifts"]) == g[f"{mode}.shifts"].tolist()
+    else:
+        assert batch["shifts"] is None
+    if f"{mode}.labels" in g.files:
+        assert np.array_equal(batch["labels"], g[f"{mode}.labels"]) and batch["labels"].dtype == g[f"{mode}.labels"].dtype
+    else:
+        assert batch["labels"] is None
+    assert batch["ids"] == g[f"{mode}.ids"].tolist()
+    if mode == "crop":
+        assert list(batch["original_images"].shape) == g["crop.original_images_shape"].tolist()
+        assert int(batch["original_images"].astype(np.int64).sum()) == int(g["crop.original_images_sum"])
+
+
+def test_batch_creator_feeds_the_step_and_line_mask_edges():
+    """Collated device tensors go straight into the batch operators; shift clamping edges of the mask kernel vs numpy."""
+    from pero_pretraining_amd import ops
+    from pero_pretraining_amd.common.dataloader import BatchCreator
+    from pero_pretraining_amd.masked_pretraining.batch_operator import BatchOperator
+    rng = np.random.default_rng(0)
+    data = [{"image": rng.integers(0, 256, (40, w, 3), dtype=np.uint8), "image2": None, "labels": rng.integers(0, 24, (w + 7) // 8).tolist(),
+             "image_id": str(i)} for i, w in enumerate((100, 64, 33))]
+    np.random.seed(2)
+    batch = BatchCreator().create_batch(data)
+    images, labels, mask = BatchOperator(torch.device("cuda"), 0.5).prepare_batch(batch)
+    assert images.is_cuda and images.shape == (3, 40, 160, 3) and labels.shape == (3, 20) and mask.shape == (3, 20)
+    assert int(images.sum()) == sum(int(d["image"].astype(np.int64).sum()) for d in data)
+    # mask kernel, exhaustive small case against the reference's slicing semantics (dataloader.py:124-138)
+    S, sub = 6, 8
+    cases = [(w1, w2, a, b) for w1 in (8, 17, 40) for w2 in (8, 33) for a in range(0, 5) for b in range(0, 5)]
+    w1 = torch.tensor([c[0] for c in cases], dtype=torch.int32, device="cuda"); w2 = torch.tensor([c[1] for c in cases], dtype=torch.int32, device="cuda")
+    l1 = torch.tensor([c[2] for c in cases], dtype=torch.int32, device="cuda"); l2 = torch.tensor([c[3] for c in cases], dtype=torch.int32, device="cuda")
+    im1, im2, sm1, sm2, shifts = (t.cpu().numpy() for t in ops.line_masks(w1, l1, S, sub, w2, l2))
+    for i, (a_w, b_w, a, b) in enumerate(cases):
+        e1 = np.ones(S, np.uint8); e1[:a] = 0; e1[a + int(np.ceil(a_w / sub)):] = 0
+        e2 = np.ones(S, np.uint8); e2[:b] = 0; e2[b + int(np.ceil(b_w / sub)):] = 0
+        sh = a - b
+        s1 = np.zeros(S, np.uint8)
+        if sh < 0:
+            s1[:sh] = 1
+        else:
+            s1[sh:] = 1
+        s2 = s1[::-1].copy()
+        s1[(s1 == 1) & (e1 == 0)] = 2; s2[(s2 == 1) & (e2 == 0)] = 2
+        assert shifts[i] == sh and np.array_equal(im1[i], e1) and np.array_equal(im2[i], e2), cases[i]
+        assert np.array_equal(sm1[i], s1) and np.array_equal(sm2[i], s2), cases[i]

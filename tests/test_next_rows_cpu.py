@@ -58,3 +58,33 @@ def test_helper_paths_match_reference(golden):
     g = golden("g13_checkpoint.npz")
     assert H.get_checkpoint_path("ckpts", 7) == str(g["checkpoint_path_7"])
     assert H.get_visualization_path("vis", 7, "trn") == str(g["visualization_path_7"])
+
+
+def _g15_lines(g):
+    widths = [int(w) for w in g["widths"]]
+    out, out2 = [], []
+    p = 0
+    for w in widths:
+        n = 10 * w * 3
+        out.append(g["lines_flat"][p:p + n].reshape(10, w, 3)); out2.append(g["lines2_flat"][p:p + n].reshape(10, w, 3))
+        p += n
+    return out, out2
+
+
+def test_oracle_collation_matches_reference_batch_creator(golden):
+    g = golden("g15_batch_creator.npz")
+    lines, lines2 = _g15_lines(g)
+    wt = O.padded_width(max(l.shape[1] for l in lines))
+    assert wt == g["pad.images"].shape[2]
+    np.random.seed(int(g["pad.seed"]))
+    lp1 = O.draw_left_paddings(lines, wt)
+    lp2 = O.draw_left_paddings(lines2, wt)
+    im1, m1 = O.collate_view(lines, lp1, wt)
+    im2, m2 = O.collate_view(lines2, lp2, wt)
+    assert np.array_equal(im1, g["pad.images"]) and np.array_equal(im2, g["pad.images2"])
+    assert np.array_equal(m1, g["pad.image_masks"]) and np.array_equal(m2, g["pad.image_masks2"])
+    shifts = [a - b for a, b in zip(lp1, lp2)]
+    assert shifts == g["pad.shifts"].tolist()
+    s1, s2 = O.shift_masks(shifts, m1, m2)
+    assert np.array_equal(s1, g["pad.shift_masks"]) and np.array_equal(s2, g["pad.shift_masks2"])
+    assert (s1 == 2).any() and (s1 == 0).any()   # the fixture exercises all three values
