@@ -150,6 +150,12 @@ int pero_vq_argmin(const float* x, const float* codebook, int64_t* indices, floa
 /* quantized[m] = x[m] + (codebook[indices[m]] - x[m])  (straight-through arithmetic, autoencoders.py:239) */
 int pero_vq_gather(const float* x, const float* codebook, const int64_t* indices, float* quantized,
                    int64_t M, int64_t D, void* stream);
+/* EMA codebook update of the tokenizer in training mode (models/autoencoders.py:225-237), in place:
+ * ema_cluster_size (K) <- Laplace-smoothed decayed counts, ema_w (K,D) <- decayed sums of the rows assigned to each
+ * code, codebook (K,D) <- ema_w / ema_cluster_size.  indices are those of pero_vq_argmin on the OLD codebook.
+ * work: f32 workspace of K + K*D elements (zeroed by the call). */
+int pero_vq_ema_update(const float* x, const int64_t* indices, float* ema_cluster_size, float* ema_w, float* codebook,
+                       float* work, int64_t M, int64_t K, int64_t D, double decay, double epsilon, void* stream);
 
 /* ---- row gather / scatter by index (boolean-mask selections of the losses) ----------------------------- */
 /* dst[i] = src[index[i]] for i < n_idx, zero rows for n_idx <= i < n_rows_out (padding) */

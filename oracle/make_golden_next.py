@@ -11,6 +11,8 @@ oracle/make_golden.py); writes small fixtures under tests/golden/:
   g14_labels.txt / g14_labels.npz  label text file written by the reference's own `save_labels` (scripts/common.py:51-54;
                                  the module cannot be imported - it needs lmdb / cv2 - so that ONE function is compiled
                                  from the module's syntax tree and run; nothing is copied)
+  g16_vq_ema.npz                 reference VectorQuantizer in TRAINING mode, two steps: indices, quantized, straight-through
+                                 gradient, EMA cluster sizes / ema_w / codebook after each step
   g15_batch_creator.npz          `BatchCreator.stack_images` / `create_batch` (common/dataloader.py:32-155) outputs for
                                  seeded ragged lines: padded images, image masks, shifts, three-valued shift masks,
                                  labels; padded and crop mode
@@ -150,7 +152,28 @@ def main():
             fix[f"{name}.original_images_shape"] = np.array(batch["original_images"].shape)
             fix[f"{name}.original_images_sum"] = np.int64(batch["original_images"].astype(np.int64).sum())
     np.savez_compressed(os.path.join(out, "g15_batch_creator.npz"), **fix)
-    print({f: os.path.getsize(os.path.join(out, f)) for f in sorted(os.listdir(out)) if f.startswith(("g12", "g13", "g14", "g15"))})
+    # ---- G16: VectorQuantizer training mode (EMA codebook update, autoencoders.py:225-237) ------------------------
+    from pero_pretraining.models import autoencoders as R_ae
+    torch.manual_seed(13)
+    vq = R_ae.VectorQuantizer(64, 32, 0.25, 0.99)
+    vq.train()
+    g = np.random.default_rng(31)
+    fix = {"codebook0": vq.embedding.weight.detach().numpy().copy(), "ema_w0": vq.ema_w.detach().numpy().copy(),
+           "ema_cluster_size0": vq.ema_cluster_size.numpy().copy(), "decay": np.float64(0.99), "commitment_cost": np.float64(0.25)}
+    for step in range(2):
+        feats = torch.from_numpy((g.standard_normal((2, 32, 1, 150)) * (1.0 + step)).astype(np.float32)).requires_grad_(True)
+        q, idx = vq(feats)
+        loss = vq.calculate_loss(q, feats) + (q * q).mean()
+        loss.backward()
+        fix[f"s{step}.features"] = feats.detach().numpy(); fix[f"s{step}.indices"] = idx.numpy()
+        fix[f"s{step}.quantized"] = q.detach().numpy(); fix[f"s{step}.loss"] = np.float64(loss.item())
+        fix[f"s{step}.grad_features"] = feats.grad.numpy().copy()
+        fix[f"s{step}.codebook"] = vq.embedding.weight.detach().numpy().copy()
+        fix[f"s{step}.ema_w"] = vq.ema_w.detach().numpy().copy()
+        fix[f"s{step}.ema_cluster_size"] = vq.ema_cluster_size.numpy().copy()
+    np.savez_compressed(os.path.join(out, "g16_vq_ema.npz"), **fix)
+
+    print({f: os.path.getsize(os.path.join(out, f)) for f in sorted(os.listdir(out)) if f.startswith(("g12", "g13", "g14", "g15", "g16"))})
 
 
 if __name__ == "__main__":

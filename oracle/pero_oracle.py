@@ -231,7 +231,7 @@ def vq_nearest(flat_input, codebook):
 
 def vq_quantize(inputs_ncht, codebook):
     """Eval-mode VectorQuantizer.forward: (N,D,1,T) -> (quantized (N,D,1,T), indices (N*T,)).
-    models/autoencoders.py:204-241 (the EMA branch is training-only and out of scope)."""
+    models/autoencoders.py:204-241 (training-mode EMA branch: vq_ema_update)."""
     x = np.asarray(inputs_ncht, dtype=np.float32)
     n, d, one, t = x.shape
     flat = np.ascontiguousarray(x.transpose(0, 2, 3, 1)).reshape(-1, d)
@@ -240,6 +240,23 @@ def vq_quantize(inputs_ncht, codebook):
     q = flat + (q - flat)  # straight-through estimator arithmetic, autoencoders.py:239 (rounds in fp32)
     q = q.reshape(n, one, t, d).transpose(0, 3, 1, 2)
     return np.ascontiguousarray(q), idx
+
+
+def vq_ema_update(flat_input, indices, ema_cluster_size, ema_w, decay=0.99, epsilon=1e-5):
+    """models/autoencoders.py:225-237 without the one-hot matrix, float32 numpy: returns (ema_cluster_size, ema_w, codebook)."""
+    f32 = np.float32
+    x = np.asarray(flat_input, dtype=f32)
+    ema_w = np.asarray(ema_w, dtype=f32)
+    K, D = ema_w.shape
+    idx = np.asarray(indices, dtype=np.int64)
+    counts = np.bincount(idx, minlength=K).astype(f32)                       # == torch.sum(encodings, 0)
+    cluster = np.asarray(ema_cluster_size, dtype=f32) * f32(decay) + f32(1 - decay) * counts
+    n = np.sum(cluster, dtype=f32)
+    cluster = (cluster + f32(epsilon)) / (n + f32(K * epsilon)) * n
+    dw = np.zeros((K, D), dtype=f32)
+    np.add.at(dw, idx, x)                                                    # == encodings.t() @ flat_input
+    ema_w = ema_w * f32(decay) + f32(1 - decay) * dw
+    return cluster.astype(f32), ema_w.astype(f32), (ema_w / cluster[:, None]).astype(f32)
 
 
 def kmeans_assign(features, centroids):

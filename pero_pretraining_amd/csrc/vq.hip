@@ -235,3 +235,69 @@ extern "C" int pero_vq_gather(const float* x, const float* codebook, const int64
   PERO_CHECK_LAUNCH("pero_vq_gather");
   return PERO_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// EMA codebook update of the tokenizer in training mode (models/autoencoders.py:225-237), without the (M, K) one-hot
+// matrix and its two GEMMs:  counts[k] = #{m : idx[m] = k},  dw[k] = sum_{idx[m] = k} x[m]  (f32 atomics),
+// cluster = cluster*decay + (1-decay)*counts;  n = sum(cluster);  cluster = (cluster + eps) / (n + K*eps) * n;
+// ema_w = ema_w*decay + (1-decay)*dw;  weight = ema_w / cluster[k].
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vq_ema_scatter_k(const float* x, const int64_t* idx, float* counts, float* dw, long long M, int D) {
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const long long k = idx[row];
+  if ((threadIdx.x & 63) == 0) atomicAdd(counts + k, 1.0f);
+  for (int c = threadIdx.x & 63; c < D; c += 64) atomicAdd(dw + k * D + c, x[row * D + c]);
+}
+// one workgroup: the sum over K runs in a fixed order (deterministic given the counts)
+__global__ __launch_bounds__(1024) void vq_ema_cluster_k(float* cluster, const float* counts, int K, float decay, float omd, float eps,
+                                                         float keps) {
+  __shared__ float red[16];
+  __shared__ float total;
+  float part = 0.f;
+  for (int k = threadIdx.x; k < K; k += 1024) {
+    const float c = cluster[k] * decay + omd * counts[k];
+    cluster[k] = c;
+    part += c;
+  }
+  part = wave_sum(part);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float n = 0.f;
+    for (int i = 0; i < 16; i++) n += red[i];
+    total = n;
+  }
+  __syncthreads();
+  const float n = total;
+  for (int k = threadIdx.x; k < K; k += 1024) cluster[k] = (cluster[k] + eps) / (n + keps) * n;
+}
+__global__ __launch_bounds__(256) void vq_ema_weights_k(float* ema_w, float* weight, const float* dw, const float* cluster, long long KD, int D,
+                                                        float decay, float omd) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= KD) return;
+  const float w = ema_w[i] * decay + omd * dw[i];
+  ema_w[i] = w;
+  weight[i] = w / cluster[i / D];
+}
+
+extern "C" int pero_vq_ema_update(const float* x, const int64_t* indices, float* ema_cluster_size, float* ema_w, float* codebook,
+                                  float* work, int64_t M, int64_t K, int64_t D, double decay, double epsilon, void* stream) {
+  PERO_REQUIRE(x && indices && ema_cluster_size && ema_w && codebook && work, "pero_vq_ema_update: null pointer");
+  PERO_REQUIRE(M > 0 && K > 0 && D > 0 && K < 2147483647LL && D < 2147483647LL, "pero_vq_ema_update: bad sizes");
+  hipStream_t st = (hipStream_t)stream;
+  float* counts = work;       // K
+  float* dw = work + K;       // K * D
+  if (hipMemsetAsync(work, 0, sizeof(float) * (size_t)(K + K * D), st) != hipSuccess) {
+    pero_set_error("pero_vq_ema_update: memset failed");
+    return PERO_E_LAUNCH;
+  }
+  hipLaunchKernelGGL(vq_ema_scatter_k, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, x, indices, counts, dw, (long long)M, (int)D);
+  // python-scalar semantics of the reference: (1 - decay) and K * epsilon are formed in double, then rounded to f32
+  const float fd = (float)decay, omd = (float)(1.0 - decay), feps = (float)epsilon, keps = (float)((double)K * epsilon);
+  hipLaunchKernelGGL(vq_ema_cluster_k, dim3(1), dim3(1024), 0, st, ema_cluster_size, counts, (int)K, fd, omd, feps, keps);
+  hipLaunchKernelGGL(vq_ema_weights_k, dim3((unsigned)((K * D + 255) / 256)), dim3(256), 0, st, ema_w, codebook, dw, ema_cluster_size,
+                     (long long)(K * D), (int)D, fd, omd);
+  PERO_CHECK_LAUNCH("pero_vq_ema_update");
+  return PERO_OK;
+}

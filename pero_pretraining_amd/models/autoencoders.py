@@ -1,8 +1,9 @@
 """VectorQuantizer with the interface of the reference's models/autoencoders.py:170-241 - the tokenizer step that
-produces the labels masked pre-training predicts (config 3: codebook 8192 x 512).  Inference path only (eval mode):
-nearest-code search by the fused exact-f32 HIP kernel (distances and one-hot matrices are never materialised),
-quantized output with the reference's straight-through arithmetic.  The EMA codebook update (training of the
-tokenizer itself, autoencoders.py:225-237) and the VGG encoder / decoder are outside the hot path."""
+produces the labels masked pre-training predicts (config 3: codebook 8192 x 512).  Nearest-code search by the fused
+exact-f32 HIP kernel (distances and one-hot matrices are never materialised), quantized output with the reference's
+straight-through arithmetic and gradient; in training mode with decay > 0 the EMA codebook update
+(autoencoders.py:225-237) runs as scatter kernels instead of two one-hot GEMMs.  The VGG encoder / decoder around the
+quantizer are outside the hot path."""
 import torch
 
 from .. import ops
@@ -38,15 +39,32 @@ class VectorQuantizer(torch.nn.Module):
         return ops.vq_argmin(flat_input.float().contiguous(), self.embedding.weight.detach().float().contiguous())
 
     def forward(self, inputs):
-        """inputs (N, D, 1, T) -> (quantized (N, D, 1, T), indices (N*T,)) like autoencoders.py:204-241."""
-        if self.training and self.decay > 0.0:
-            raise NotImplementedError("EMA codebook training is outside the HIP hot path; call .eval() for label production")
+        """inputs (N, D, 1, T) -> (quantized (N, D, 1, T), indices (N*T,)) like autoencoders.py:204-241.
+        The gradient of `quantized` flows straight through to `inputs` (autoencoders.py:239).  Training mode with
+        decay > 0 updates ema_cluster_size / ema_w / embedding.weight IN PLACE after quantizing with the old codebook
+        (the reference re-creates the two nn.Parameters every step, which detaches them from any optimizer and from
+        DDP - not reproduced; values are the same)."""
         x = inputs.permute(0, 2, 3, 1).contiguous()
-        shape = x.shape
-        flat = x.view(-1, self.embeddings_dim).float()
-        idx = self.nearest(flat)
-        q = ops.vq_gather(flat, self.embedding.weight.detach().float().contiguous(), idx).view(shape)
-        return q.permute(0, 3, 1, 2).contiguous(), idx
+        flat = x.reshape(-1, self.embeddings_dim).float()
+        q, idx = _QuantizeFn.apply(flat, self)
+        return q.view(x.shape).permute(0, 3, 1, 2).contiguous(), idx
+
+
+class _QuantizeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, flat, vq):
+        flat = flat.detach().contiguous()
+        weight = vq.embedding.weight.detach()
+        idx = vq.nearest(flat)
+        q = ops.vq_gather(flat, weight.float().contiguous(), idx)
+        if vq.training and vq.decay > 0.0:
+            ops.vq_ema_update(flat, idx, vq.ema_cluster_size, vq.ema_w.data, vq.embedding.weight.data, vq.decay, vq.epsilon)
+        ctx.mark_non_differentiable(idx)
+        return q, idx
+
+    @staticmethod
+    def backward(ctx, dq, _didx):
+        return dq, None
 
 
 def kmeans_labels(features, centroids):

@@ -225,6 +225,15 @@ def vq_gather(x, codebook, idx):
     return q
 
 
+def vq_ema_update(x, idx, ema_cluster_size, ema_w, codebook, decay, epsilon):
+    """In-place EMA codebook update (models/autoencoders.py:225-237); all tensors f32 contiguous on the device."""
+    M, D = x.shape
+    K = codebook.shape[0]
+    work = torch.empty(K + K * D, device=x.device, dtype=torch.float32)
+    call("pero_vq_ema_update", ptr(x), ptr(idx), ptr(ema_cluster_size), ptr(ema_w), ptr(codebook), ptr(work), M, K, D,
+         float(decay), float(epsilon), stream())
+
+
 def gather_rows(src, index, n_rows_out=None, out=None):
     n_idx = index.numel()
     n_out = n_idx if n_rows_out is None else n_rows_out

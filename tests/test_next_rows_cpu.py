@@ -88,3 +88,43 @@ def test_oracle_collation_matches_reference_batch_creator(golden):
     s1, s2 = O.shift_masks(shifts, m1, m2)
     assert np.array_equal(s1, g["pad.shift_masks"]) and np.array_equal(s2, g["pad.shift_masks2"])
     assert (s1 == 2).any() and (s1 == 0).any()   # the fixture exercises all three values
+
+
+def test_oracle_vq_ema_update_matches_reference(golden):
+    g = golden("g16_vq_ema.npz")
+    cb, ew, cs = g["codebook0"], g["ema_w0"], g["ema_cluster_size0"]
+    for step in range(2):
+        feats = g[f"s{step}.features"]
+        flat = np.ascontiguousarray(feats.transpose(0, 2, 3, 1)).reshape(-1, 32)
+        idx, _ = O.vq_nearest(flat, cb)
+        assert np.array_equal(idx, g[f"s{step}.indices"])
+        q, _ = O.vq_quantize(feats, cb)
+        assert np.abs(q - g[f"s{step}.quantized"]).max() < 1e-6
+        cs, ew, cb = O.vq_ema_update(flat, idx, cs, ew, float(g["decay"]))
+        assert np.abs(cs - g[f"s{step}.ema_cluster_size"]).max() < 1e-6
+        assert np.abs(ew - g[f"s{step}.ema_w"]).max() < 1e-5
+        assert np.abs(cb - g[f"s{step}.codebook"]).max() < 1e-4 * np.abs(g[f"s{step}.codebook"]).max()
+        cb, ew, cs = g[f"s{step}.codebook"], g[f"s{step}.ema_w"], g[f"s{step}.ema_cluster_size"]  # next step: reference state
+
+
+def test_label_text_and_record_formats(golden, tmp_path):
+    """Host-side formats of the label pipeline: byte-identical to the file the reference's own save_labels wrote."""
+    from pero_pretraining_amd.scripts import labels as L
+    g = golden("g14_labels.npz")
+    ids, lens, flat = g["ids"].tolist(), g["lens"].tolist(), g["labels"].tolist()
+    data, p = {}, 0
+    for i, n in zip(ids, lens):
+        data[i] = flat[p:p + n]; p += n
+    out = tmp_path / "labels.txt"
+    L.save_labels(data, str(out))
+    ref = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g14_labels.txt")
+    assert out.read_bytes() == open(ref, "rb").read()
+    # the file parses back (common/dataset.py:_parse_line) and converts to LMDB records (convert_gt_to_lmdb.py:28-39)
+    parsed = [L.parse_line(l) for l in open(ref)]
+    assert [p[0] for p in parsed] == ids and [len(p[1]) for p in parsed] == lens
+    store = {}
+    n = L.convert_labels_file(ref, lambda k, v: store.__setitem__(k, v), offset=5)
+    assert n == 3 and sorted(store) == [b"         5", b"         6", b"         7"]   # the unlabeled 4th line is skipped
+    assert store[b"         6"] == ('{"image": "b/line_1", "labels": [' + ", ".join(f'"{v}"' for v in data["b/line_1"]) + "]}").encode()
+    assert L.parse_label_record(store[b"         7"]) == ("c-2.png", [str(data["c-2.png"][0])])
+    assert L.parse_label_record(b'{"images": ["a", "b"], "labels": ["1"]}') == (["a", "b"], ["1"])
