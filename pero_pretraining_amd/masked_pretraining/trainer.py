@@ -77,9 +77,15 @@ class Trainer:
         with autocast(self.bfloat16):
             output = self.model.forward(images, labels, mask)
         loss = output["loss"]
+        seed = None
         if self.data_parallel is not None:
+            if self.data_parallel.loss_weighting == "global_mean":
+                if getattr(self.model.loss, "unmasked_weight", None) is not None:
+                    raise ValueError("loss_weighting='global_mean' covers the masked mean only (unmasked_weight must be None)")
+                m = mask if isinstance(mask, torch.Tensor) else torch.as_tensor(mask)
+                seed = self.data_parallel.backward_seed((m.to(loss.device) == 1).sum())
             self.data_parallel.begin_backward()
-        loss.backward()
+        loss.backward(seed)
         if self.data_parallel is not None:
             self.data_parallel.finish_backward()
         return loss.detach()

@@ -10,10 +10,13 @@ layer's backward kernels are enqueued (the backbone calls `_on_layer_grads_ready
 of layer i overlaps the backward compute of layers i-1..0.  The sum is turned into a mean by the fused
 Adam kernel's `grad_scale` (no extra pass over the gradients).
 
-Loss semantics under sharding (stated, as SURVEY.md section 8e asks): each rank's loss is the mean over ITS masked
-positions and gradients are averaged over ranks (mean of per-rank means - identical to
-torch DistributedDataParallel; equals the single-process gradient when every rank has the same number
-of masked positions).  VICReg statistics are per rank.
+Loss semantics under sharding (stated, as SURVEY.md section 8e asks).  loss_weighting="rank_mean" (default): each
+rank's loss is the mean over ITS masked positions and gradients are averaged over ranks (mean of per-rank means -
+identical to torch DistributedDataParallel; equals the single-process gradient when every rank has the same number of
+masked positions).  loss_weighting="global_mean": the masked counts are all-reduced (8 bytes, on the device, no host
+sync) and rank r's backward is seeded with n_r * world / n_global, so the averaged gradient IS the gradient of the mean
+over all masked positions of the global batch - exactly what the single-process reference computes on that batch.
+VICReg statistics are per rank.
 """
 import torch
 import torch.distributed as dist
@@ -63,7 +66,10 @@ class DataParallel:
         dp = DataParallel(model, optimizer); trainer = Trainer(..., data_parallel=dp)
     """
 
-    def __init__(self, model, optimizer, process_group=None, overlap=True, layers_per_bucket=2):
+    def __init__(self, model, optimizer, process_group=None, overlap=True, layers_per_bucket=2, loss_weighting="rank_mean"):
+        if loss_weighting not in ("rank_mean", "global_mean"):
+            raise ValueError(f"Unknown loss weighting: {loss_weighting}")
+        self.loss_weighting = loss_weighting
         self.model, self.optimizer, self.group = model, optimizer, process_group
         self.layers_per_bucket = max(1, int(layers_per_bucket))  # 2 layers = 25 MB f32 at d=512
         self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -110,6 +116,15 @@ class DataParallel:
         if stage % lpb == 0:  # lowest layer of its group: the whole group [stage, stage + lpb) is complete
             for s in range(stage, min(stage + lpb, self.num_layers)):
                 self._reduce(s)
+
+    def backward_seed(self, local_count):
+        """d(loss)/d(loss) seed for this rank's backward: None (= 1) for rank_mean, n_r * world / n_global for
+        global_mean.  local_count: 0-dim tensor (number of positions in this rank's mean), stays on its device."""
+        if self.loss_weighting == "rank_mean" or not self.active:
+            return None
+        total = local_count.detach().to(torch.float32).clone()
+        dist.all_reduce(total, op=dist.ReduceOp.SUM, group=self.group)
+        return local_count.detach().to(torch.float32) * float(self.world_size) / total
 
     def begin_backward(self):
         self._pending, self._done = [], set()

@@ -31,7 +31,7 @@ def _data(rank):
     return torch.from_numpy(images).cuda(), torch.from_numpy(labels).cuda(), torch.from_numpy(mask).cuda()
 
 
-def _worker(rank, world, port, out_q):
+def _worker(rank, world, port, out_q, weighting="rank_mean"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
@@ -46,7 +46,7 @@ def _worker(rank, world, port, out_q):
             for p in model.parameters():
                 p.add_(0.1)
     opt = FusedAdam(model.parameters(), lr=1e-3)
-    dp = DataParallel(model, opt)
+    dp = DataParallel(model, opt, loss_weighting=weighting)
     trainer = Trainer(None, model, None, opt, WarmupSchleduler(opt, 1e-3, 0, 1), data_parallel=dp)
     offs = np.array([5, 17, 300]) + rank
     model.backbone.set_offsets(offs)
@@ -99,4 +99,29 @@ def test_two_rank_step_matches_mean_of_single_rank_gradients():
         ref = g if ref is None else {k: ref[k] + g[k] for k in g}
     for k in ref:
         want = ref[k] / 2
+        assert np.abs(grads[k] - want).max() <= 1e-5 * max(np.abs(want).max(), 1e-3), k
+
+
+def test_two_rank_global_mean_equals_single_process_on_the_whole_batch():
+    """loss_weighting="global_mean": ranks hold different numbers of masked positions (18 and 15); the averaged gradient
+    must be the gradient of ONE mean over all 33 - what the single-process reference computes on the 6-line batch."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, "global_mean")) for r in range(2)]
+    for p in procs:
+        p.start()
+    _, grads, same = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert same
+    model = _build()
+    model.backbone.set_offsets(np.concatenate([np.array([5, 17, 300]) + r for r in range(2)]))
+    parts = [_data(r) for r in range(2)]
+    images, labels, mask = (torch.cat([p[i] for p in parts]) for i in range(3))
+    assert int(parts[0][2].sum()) != int(parts[1][2].sum())
+    model(images, labels, mask)["loss"].backward()
+    for k, p in model.named_parameters():
+        want = p.grad.cpu().numpy()
         assert np.abs(grads[k] - want).max() <= 1e-5 * max(np.abs(want).max(), 1e-3), k

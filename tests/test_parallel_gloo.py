@@ -124,3 +124,20 @@ def test_bucketed_all_reduce_world2_overlap():
 
 def test_all_reduce_world2_no_overlap():
     mp.spawn(_worker, args=(2, _free_port(), False), nprocs=2, join=True)
+
+
+def _seed_worker(rank, world, port):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    model = _Model(2)
+    counts = [3, 5]
+    dp = DataParallel(model, _FlatOpt(model), loss_weighting="global_mean")
+    seed = dp.backward_seed(torch.tensor(counts[rank]))
+    assert abs(float(seed) - counts[rank] * world / sum(counts)) < 1e-7     # 0.75 / 1.25: mean of seeds over ranks == 1
+    assert DataParallel(model, _FlatOpt(model)).backward_seed(torch.tensor(counts[rank])) is None
+    dist.destroy_process_group()
+
+
+def test_global_mean_backward_seed_world2():
+    mp.spawn(_seed_worker, args=(2, _free_port()), nprocs=2, join=True)
