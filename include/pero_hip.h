@@ -40,6 +40,7 @@ extern "C" {
 #define PERO_GEMM_TILE128 64     /* benchmarking: force the 128x128-tile bf16 kernel */
 #define PERO_GEMM_TILE256 128    /* benchmarking: force the 256x256-tile bf16 kernel (when the shape allows) */
 #define PERO_GEMM_TILE_S 256     /* benchmarking: force the 128x128x32 four-workgroups-per-CU kernel */
+#define PERO_GEMM_TILE_V 512     /* prefer the 256x256x64 one-workgroup-per-CU kernel (whole GPU to itself: forward pass) */
 #define PERO_GEMM_FORCE_GENERIC 32 /* testing: take the exact-f32 generic kernel even when the fast bf16 kernel applies */
 
 const char* pero_last_error(void);

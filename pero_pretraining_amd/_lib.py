@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libpero_hip.so")
 PERO_F32, PERO_BF16 = 0, 1
 LN_BWD_BLOCKS = 512
 GEMM_RELU, GEMM_ATOMIC, GEMM_ACCUM, GEMM_TRANS_A, GEMM_TRANS_B, GEMM_FORCE_GENERIC = 1, 2, 4, 8, 16, 32
+GEMM_TILE_V = 512  # prefer the 256x256x64 kernel: products that have the GPU to themselves (forward pass)
 GEMM_TILE128, GEMM_TILE256 = 64, 128
 
 _vp, _i64, _i32, _f32, _f64 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_double

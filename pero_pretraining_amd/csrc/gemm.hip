@@ -417,6 +417,7 @@ extern "C" int pero_gemm(const void* A, const void* B, void* C, const float* bia
     //  256-tile one, whose epilogue is not deferred - it would need 256 accumulator VGPRs; 256 tiles stay opt-in)
     bool use256 = false;
     (void)t256;
+    const int k_split_req = k_split;
     if (atomic && k_split == 0) {
       long long ks = (g_splitk_items + t128 - 1) / t128;
       if (ks > K / 512) ks = K / 512;
@@ -430,6 +431,18 @@ extern "C" int pero_gemm(const void* A, const void* B, void* C, const float* bia
     } else if (k_split < 1) {
       k_split = 1;
     }
+    if (g_gemm_policy == 13 && atomic && can256 && !forced0 && out_dtype == PERO_F32) {  // experiment: 256x256x64 split-K tiles
+      long long ks2 = k_split_req;
+      if (ks2 == 0) {
+        ks2 = (256 + t256 - 1) / t256;
+        if (ks2 > K / 256) ks2 = K / 256;
+        if (ks2 < 1) ks2 = 1;
+      }
+      if (pero_launch_gemm_v256(p, batch, (int)ks2, ta, tb, true, st)) {
+        PERO_CHECK_LAUNCH("pero_gemm(v256 split-K)");
+        return PERO_OK;
+      }
+    }
     if (!forced0 && (g_gemm_policy == 4 || ((g_gemm_policy == 0 || g_gemm_policy >= 7) && atomic)) &&
         pero_launch_gemm_o128(p, batch, k_split, ta, tb, out_dtype == PERO_F32, st)) {
       PERO_CHECK_LAUNCH("pero_gemm(bf16 o128)");
@@ -439,11 +452,19 @@ extern "C" int pero_gemm(const void* A, const void* B, void* C, const float* bia
       PERO_CHECK_LAUNCH("pero_gemm(bf16 p128)");
       return PERO_OK;
     }
+    if (g_gemm_policy == 12 && !forced0 && !atomic && pero_launch_gemm_w256(p, batch, k_split, ta, tb, out_dtype == PERO_F32, st)) {
+      PERO_CHECK_LAUNCH("pero_gemm(w256)");
+      return PERO_OK;
+    }
+    if ((g_gemm_policy == 10 || g_gemm_policy == 12 || (g_gemm_policy == 11 && K >= 1024) || (g_gemm_policy == 0 && (flags & PERO_GEMM_TILE_V))) && !forced0 && !atomic && pero_launch_gemm_v256(p, batch, k_split, ta, tb, out_dtype == PERO_F32, st)) {
+      PERO_CHECK_LAUNCH("pero_gemm(v256)");
+      return PERO_OK;
+    }
     if (g_gemm_policy == 8 && !forced0 && !atomic && pero_launch_gemm_q256(p, batch, k_split, ta, tb, out_dtype == PERO_F32, st)) {
       PERO_CHECK_LAUNCH("pero_gemm(bf16 q256)");
       return PERO_OK;
     }
-    if ((g_gemm_policy == 7 || g_gemm_policy == 0) && !forced0 && !atomic && pero_launch_gemm_r256(p, batch, k_split, ta, tb, out_dtype == PERO_F32, st)) {
+    if ((g_gemm_policy == 7 || g_gemm_policy == 0 || g_gemm_policy == 11) && !forced0 && !atomic && pero_launch_gemm_r256(p, batch, k_split, ta, tb, out_dtype == PERO_F32, st)) {
       PERO_CHECK_LAUNCH("pero_gemm(bf16 r256)");
       return PERO_OK;
     }

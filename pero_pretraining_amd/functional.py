@@ -14,7 +14,7 @@ import math
 import torch
 
 from . import lowp, ops
-from ._lib import GEMM_ATOMIC, GEMM_TRANS_A, GEMM_TRANS_B
+from ._lib import GEMM_ATOMIC, GEMM_TILE_V, GEMM_TRANS_A, GEMM_TRANS_B
 
 LN_EPS = 1e-5
 
@@ -33,9 +33,12 @@ def ensure_grad(p):
     return p.grad
 
 
+FWD_TILE_FLAGS = GEMM_TILE_V  # forward products run alone on the GPU (no side-stream kernels beside them): 256x256x64 tiles
+
+
 def linear_fwd(x, w, b, dtype, residual=None, relu=False, out_dtype=None):
     return ops.gemm(x, lowp.weight(w, dtype), bias=None if b is None else b.detach(), residual=residual, relu=relu,
-                    out_dtype=out_dtype)
+                    out_dtype=out_dtype, extra_flags=FWD_TILE_FLAGS)
 
 
 SIDE_STREAM_DW = True  # weight / bias gradients on a second HIP stream (they are off the backward critical path)
