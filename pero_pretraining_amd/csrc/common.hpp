@@ -13,6 +13,18 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 
 #define LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
 
+// Two transposed 8-byte LDS reads (ds_read_b64_tr_b16) -> one 8 x bf16 MFMA operand.  The halves are joined by a vector
+// CONCATENATION of two 64-bit values: assembling the operand element by element from the 4 x i16 results made the
+// compiler copy every dword (4 v_mov_b32 per fragment: 64 per k-step in the K-major GEMM loops).
+__device__ __forceinline__ bf8v lds_tr16_pair(const unsigned char* a, const unsigned char* b) {
+  typedef int i2v __attribute__((ext_vector_type(2)));
+  typedef int i4v __attribute__((ext_vector_type(4)));
+  const i2v lo = __builtin_bit_cast(i2v, __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s4v, a)));
+  const i2v hi = __builtin_bit_cast(i2v, __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s4v, b)));
+  const i4v v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+  return __builtin_bit_cast(bf8v, v);
+}
+
 __device__ __forceinline__ float bf2f(bf16raw b) { return __uint_as_float(((unsigned)b) << 16); }
 __device__ __forceinline__ bf16raw f2bf(float f) {  // round-to-nearest-even, NaN stays NaN (v_cvt_pk_bf16_f32)
   __bf16 h = (__bf16)f;

@@ -434,7 +434,10 @@ extern "C" int pero_gemm(const void* A, const void* B, void* C, const float* bia
     if (g_gemm_policy == 13 && atomic && can256 && !forced0 && out_dtype == PERO_F32) {  // experiment: 256x256x64 split-K tiles
       long long ks2 = k_split_req;
       if (ks2 == 0) {
-        ks2 = (256 + t256 - 1) / t256;
+        ks2 = 256 / t256;                       // one round of workgroups, slices in multiples of 8 (one per XCD)
+        if (ks2 >= 8) ks2 = (ks2 / 8) * 8;
+        else if (ks2 >= 4) ks2 = 4;
+        else if (ks2 >= 2) ks2 = 2;
         if (ks2 > K / 256) ks2 = K / 256;
         if (ks2 < 1) ks2 = 1;
       }

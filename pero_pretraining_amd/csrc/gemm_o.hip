@@ -106,36 +106,54 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_o128(GemmP p, int ks_xcd) {
 #pragma unroll
     for (int j = 0; j < 4; j++) acc[i][j] = (f4v){0.f, 0.f, 0.f, 0.f};
 
+  // Main loop rotated by half a stage (see gemm_v.hip): the fragments of the next half-step are read from LDS while the
+  // current one multiplies, the stage barrier sits between the two half-steps of a stage, so every wave leaves the barrier
+  // into MFMAs.  With two workgroups of four waves per CU (two waves per SIMD) the plain form serialised the LDS-read and
+  // the MFMA phases almost completely.
+  auto half_step = [&](const unsigned char* nsa, const unsigned char* nsb, int nks, bf8v (&fa)[4], bf8v (&fb)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) {  // swapped operands: D[n][m], so a lane holds 4 consecutive n of one m
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        if (i == 3) {
+          fb[j] = TB ? ofrag_kmajor(nsb, wn * 64 + j * 16, nks, lane) : ofrag_rowmajor(nsb, wn * 64 + j * 16, nks, lane);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, TB ? 2 : 1, 0);
+        }
+      }
+      fa[i] = TA ? ofrag_kmajor(nsa, wm * 64 + i * 16, nks, lane) : ofrag_rowmajor(nsa, wm * 64 + i * 16, nks, lane);
+      if (i < 3) __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, TA ? 2 : 1, 0);
+    }
+  };
+  bf8v fa[4], fb[4];
   if (nk > 0) {
     ostage_glds<TA>(A, p.lda, tm0, kbeg, smem, tid);
     ostage_glds<TB>(B, p.ldb, tn0, kbeg, smem + O_OPBYTES, tid);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();
+    if (nk > 1) {
+      ostage_glds<TA>(A, p.lda, tm0, kbeg + O_BK, smem + O_BUFBYTES, tid);
+      ostage_glds<TB>(B, p.ldb, tn0, kbeg + O_BK, smem + O_BUFBYTES + O_OPBYTES, tid);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      fa[i] = TA ? ofrag_kmajor(smem, wm * 64 + i * 16, 0, lane) : ofrag_rowmajor(smem, wm * 64 + i * 16, 0, lane);
+      fb[i] = TB ? ofrag_kmajor(smem + O_OPBYTES, wn * 64 + i * 16, 0, lane) : ofrag_rowmajor(smem + O_OPBYTES, wn * 64 + i * 16, 0, lane);
+    }
   }
   for (int t = 0; t < nk; t++) {
-    // tile t has landed (own DMA drained, then barrier: everyone's); all waves are past their reads of the
-    // other buffer (tile t-1), so it can be refilled while tile t is multiplied
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    const unsigned char* sa = smem + (t & 1) * O_BUFBYTES;
-    const unsigned char* sb = sa + O_OPBYTES;
-    if (t + 1 < nk) {
-      unsigned char* da = smem + ((t + 1) & 1) * O_BUFBYTES;
-      ostage_glds<TA>(A, p.lda, tm0, kbeg + (long long)(t + 1) * O_BK, da, tid);
-      ostage_glds<TB>(B, p.ldb, tn0, kbeg + (long long)(t + 1) * O_BK, da + O_OPBYTES, tid);
+    unsigned char* s0 = smem + (t & 1) * O_BUFBYTES;         // stage t
+    unsigned char* s1 = smem + ((t + 1) & 1) * O_BUFBYTES;   // stage t + 1
+    half_step(s0, s0 + O_OPBYTES, 1, fa, fb);                 // (t, 0) multiplies, (t, 1) is read
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // own DMA of stage t + 1
+    lds_barrier();                                            // everyone's; every wave has finished reading stage t
+    if (t + 2 < nk) {
+      ostage_glds<TA>(A, p.lda, tm0, kbeg + (long long)(t + 2) * O_BK, s0, tid);
+      ostage_glds<TB>(B, p.ldb, tn0, kbeg + (long long)(t + 2) * O_BK, s0 + O_OPBYTES, tid);
     }
-#pragma unroll
-    for (int ks = 0; ks < 2; ks++) {
-      bf8v fa[4], fb[4];
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        fa[i] = TA ? ofrag_kmajor(sa, wm * 64 + i * 16, ks, lane) : ofrag_rowmajor(sa, wm * 64 + i * 16, ks, lane);
-        fb[i] = TB ? ofrag_kmajor(sb, wn * 64 + i * 16, ks, lane) : ofrag_rowmajor(sb, wn * 64 + i * 16, ks, lane);
-      }
-#pragma unroll
-      for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int j = 0; j < 4; j++)  // swapped operands: D[n][m], so a lane holds 4 consecutive n of one m
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-    }
+    half_step(s1, s1 + O_OPBYTES, 0, fa, fb);                 // (t, 1) multiplies, (t + 1, 0) is read (unused after the last stage)
   }
   __syncthreads();  // all fragment reads done before the epilogue reuses the LDS
 

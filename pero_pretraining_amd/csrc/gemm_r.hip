@@ -97,42 +97,52 @@ __global__ __launch_bounds__(512, 4) void gemm_bf16_r256(GemmP p) {
 #pragma unroll
     for (int j = 0; j < 4; j++) acc[i][j] = (f4v){0.f, 0.f, 0.f, 0.f};
 
-  // R_STAGES-slot LDS-DMA ring, R_STAGES - 1 k-steps in flight: the DMA stream is latency-bound (bytes in flight per CU /
-  // ~2 us loaded L2+HBM latency); with the former double buffer only 24 KiB per workgroup were ever in flight.
-#pragma unroll
-  for (int s = 0; s < R_STAGES - 1; s++)
-    if (s < nk) {
-      rstage_glds<TA, 256>(A, p.lda, tm0, kbeg + (long long)s * R_BK, smem + s * R_BUFBYTES, tid);
-      rstage_glds<TB, 128>(B, p.ldb, tn0, kbeg + (long long)s * R_BK, smem + s * R_BUFBYTES + R_OPBYTES, tid);
-    }
-  int slot = 0;
-  for (int t = 0; t < nk; t++) {
-    // each wave issues 3 DMA instructions per stage; stages t+1 .. t+R_STAGES-2 may stay in flight
-    const int ahead = nk - 1 - t;
-    if (R_STAGES >= 4 && ahead >= 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else if (R_STAGES >= 3 && ahead >= 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // Main loop, software-pipelined by one stage with a TWO-slot ring: at barrier t every wave holds the fragments of stage t
+  // in registers (read during the previous iteration), so the slot of stage t can be refilled (DMA of stage t + 2) and the
+  // 16 MFMAs of stage t start at once; the fragments of stage t + 1 (landed: waited for before the barrier) are read
+  // between them, each register set as soon as its last MFMA has issued.  In the plain form (barrier, 8 fragment reads,
+  // 16 MFMAs) all waves left the barrier together into the LDS-read phase and the MFMA pipe waited.
+  bf8v fa[4], fb[4];
+  if (nk > 0) {
+    rstage_glds<TA, 256>(A, p.lda, tm0, kbeg, smem, tid);
+    rstage_glds<TB, 128>(B, p.ldb, tn0, kbeg, smem + R_OPBYTES, tid);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_barrier();
-    const unsigned char* sa = smem + slot * R_BUFBYTES;
-    const unsigned char* sb = sa + R_OPBYTES;
-    if (t + R_STAGES - 1 < nk) {
-      const int ns = slot == 0 ? R_STAGES - 1 : slot - 1;  // the slot of k-step t-1: every wave is past it
-      unsigned char* da = smem + ns * R_BUFBYTES;
-      rstage_glds<TA, 256>(A, p.lda, tm0, kbeg + (long long)(t + R_STAGES - 1) * R_BK, da, tid);
-      rstage_glds<TB, 128>(B, p.ldb, tn0, kbeg + (long long)(t + R_STAGES - 1) * R_BK, da + R_OPBYTES, tid);
+    if (nk > 1) {
+      rstage_glds<TA, 256>(A, p.lda, tm0, kbeg + R_BK, smem + R_BUFBYTES, tid);
+      rstage_glds<TB, 128>(B, p.ldb, tn0, kbeg + R_BK, smem + R_BUFBYTES + R_OPBYTES, tid);
     }
-    slot = slot == R_STAGES - 1 ? 0 : slot + 1;
-    bf8v fa[4], fb[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      fa[i] = TA ? rfrag_kmajor<256>(sa, wm * 64 + i * 16, lane) : rfrag_rowmajor(sa, wm * 64 + i * 16, lane);
-      fb[i] = TB ? rfrag_kmajor<128>(sb, wn * 64 + i * 16, lane) : rfrag_rowmajor(sb, wn * 64 + i * 16, lane);
+      fa[i] = TA ? rfrag_kmajor<256>(smem, wm * 64 + i * 16, lane) : rfrag_rowmajor(smem, wm * 64 + i * 16, lane);
+      fb[i] = TB ? rfrag_kmajor<128>(smem + R_OPBYTES, wn * 64 + i * 16, lane) : rfrag_rowmajor(smem + R_OPBYTES, wn * 64 + i * 16, lane);
     }
+  }
+  for (int t = 0; t < nk; t++) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // own DMA of stage t + 1
+    lds_barrier();                                    // everyone's; every wave holds stage t in registers
+    if (t + 2 < nk) {
+      unsigned char* da = smem + (t & 1) * R_BUFBYTES;
+      rstage_glds<TA, 256>(A, p.lda, tm0, kbeg + (long long)(t + 2) * R_BK, da, tid);
+      rstage_glds<TB, 128>(B, p.ldb, tn0, kbeg + (long long)(t + 2) * R_BK, da + R_OPBYTES, tid);
+    }
+    const unsigned char* nsa = smem + ((t + 1) & 1) * R_BUFBYTES;  // stage t + 1 (stale data after the last stage: unused)
+    const unsigned char* nsb = nsa + R_OPBYTES;
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < 4; i++) {
 #pragma unroll
-      for (int j = 0; j < 4; j++)
+      for (int j = 0; j < 4; j++) {
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        if (i == 3) {
+          fb[j] = TB ? rfrag_kmajor<128>(nsb, wn * 64 + j * 16, lane) : rfrag_rowmajor(nsb, wn * 64 + j * 16, lane);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, TB ? 2 : 1, 0);
+        }
+      }
+      fa[i] = TA ? rfrag_kmajor<256>(nsa, wm * 64 + i * 16, lane) : rfrag_rowmajor(nsa, wm * 64 + i * 16, lane);
+      if (i < 3) __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, TA ? 2 : 1, 0);
+    }
   }
 
   // ---- epilogue: f32 accumulators -> LDS in two 64-row halves -> whole 256-byte row segments to HBM (16-byte lanes).

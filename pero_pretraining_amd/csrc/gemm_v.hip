@@ -25,11 +25,7 @@ __device__ __forceinline__ bf8v vfrag_kmajor(const unsigned char* base, int col,
   const int i = lane & 15;
   const int krow = ks * 32 + 8 * (lane >> 4) + (i >> 2);
   const unsigned char* a = base + krow * 512 + ((((col >> 4) ^ fk(krow))) << 5) + 8 * (i & 3);
-  s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s4v, a));
-  s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s4v, a + 4 * 512));
-  typedef short s8v __attribute__((ext_vector_type(8)));
-  s8v v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-  return __builtin_bit_cast(bf8v, v);
+  return lds_tr16_pair(a, a + 4 * 512);
 }
 // 256-row operand tile x 64 k = 32 pieces of 1 KiB: two LDS-DMA instructions per wave
 template <bool TR>
@@ -53,22 +49,30 @@ __device__ __forceinline__ void vstage_glds(const bf16raw* X, long long ld, long
 }
 
 template <bool TA, bool TB, bool OUTF32>
-__global__ __launch_bounds__(1024, 4) void gemm_bf16_v256(GemmP p) {
+__global__ __launch_bounds__(1024, 4) void gemm_bf16_v256(GemmP p, int ks_xcd) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 2, wn = wave & 3;
   const int ntn = (int)(p.N / V_BN);
   const int nt = (int)(p.M / V_BM) * ntn;
   const int bid = blockIdx.x;
-  const int q = nt >> 3, r8 = nt & 7, xcd = bid & 7, loc = bid >> 3;
-  const int id = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + loc;
+  int id, zslice;
+  if (ks_xcd > 0) {  // split-K: one k-slice per XCD, all of its tiles on that XCD's L2 (as gemm_bf16_o128)
+    const int xcd = bid & 7, r = bid >> 3;
+    if (ks_xcd >= 8) { const int per = ks_xcd >> 3; zslice = xcd * per + (r % per); id = r / per; }
+    else { zslice = xcd % ks_xcd; id = r * (8 / ks_xcd) + xcd / ks_xcd; }
+  } else {
+    const int q = nt >> 3, r8 = nt & 7, xcd = bid & 7, loc = bid >> 3;
+    id = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + loc;
+    zslice = blockIdx.z;
+  }
   const long long tm0 = (long long)(id / ntn) * V_BM, tn0 = (long long)(id % ntn) * V_BN;
   const int b = blockIdx.y;
   const long long bo = b / p.binner, bi = b % p.binner;
   const bf16raw* A = (const bf16raw*)p.A + bo * p.sAo + bi * p.sAi;
   const bf16raw* B = (const bf16raw*)p.B + bo * p.sBo + bi * p.sBi;
   const long long coff = bo * p.sCo + bi * p.sCi;
-  const long long kbeg = (long long)blockIdx.z * p.kchunk;
+  const long long kbeg = (long long)zslice * p.kchunk;
   long long kend = kbeg + p.kchunk;
   if (kend > p.K) kend = p.K;
   const int nk = (int)((kend - kbeg) / V_BK);
@@ -79,34 +83,55 @@ __global__ __launch_bounds__(1024, 4) void gemm_bf16_v256(GemmP p) {
 #pragma unroll
     for (int j = 0; j < 4; j++) acc[i][j] = (f4v){0.f, 0.f, 0.f, 0.f};
 
+  // Main loop, rotated by half a stage.  A stage (BK = 64) is two half-steps of 16 MFMAs per wave; the fragments of the
+  // NEXT half-step are read from LDS while the current one multiplies (each register set is refilled as soon as its last
+  // MFMA has issued), and the stage barrier sits between the two half-steps.  So the code after the barrier starts with
+  // MFMAs on fragments already in registers: in the plain form (barrier, 8 fragment reads, 16 MFMAs) all sixteen waves
+  // leave the barrier together, read together and multiply together - the "LDS reads only" ablation cost 64 of 145 us.
+  auto half_step = [&](const unsigned char* nsa, const unsigned char* nsb, int nks, bf8v (&fa)[4], bf8v (&fb)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        if (i == 3) {
+          fb[j] = TB ? vfrag_kmajor(nsb, wn * 64 + j * 16, nks, lane) : vfrag_rowmajor(nsb, wn * 64 + j * 16, nks, lane);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);             // 1 MFMA
+          __builtin_amdgcn_sched_group_barrier(0x100, TB ? 2 : 1, 0);    // then the LDS read(s) of the register set it freed
+        }
+      }
+      fa[i] = TA ? vfrag_kmajor(nsa, wm * 64 + i * 16, nks, lane) : vfrag_rowmajor(nsa, wm * 64 + i * 16, nks, lane);
+      if (i < 3) __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);       // 4 MFMAs of row i
+      __builtin_amdgcn_sched_group_barrier(0x100, TA ? 2 : 1, 0);        // then the read(s) that refill fa[i]
+    }
+  };
+  bf8v fa[4], fb[4];
   if (nk > 0) {
     vstage_glds<TA>(A, p.lda, tm0, kbeg, smem, tid);
     vstage_glds<TB>(B, p.ldb, tn0, kbeg, smem + V_ABYTES, tid);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();
+    if (nk > 1) {
+      vstage_glds<TA>(A, p.lda, tm0, kbeg + V_BK, smem + V_BUFBYTES, tid);
+      vstage_glds<TB>(B, p.ldb, tn0, kbeg + V_BK, smem + V_BUFBYTES + V_ABYTES, tid);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      fa[i] = TA ? vfrag_kmajor(smem, wm * 64 + i * 16, 0, lane) : vfrag_rowmajor(smem, wm * 64 + i * 16, 0, lane);
+      fb[i] = TB ? vfrag_kmajor(smem + V_ABYTES, wn * 64 + i * 16, 0, lane) : vfrag_rowmajor(smem + V_ABYTES, wn * 64 + i * 16, 0, lane);
+    }
   }
   for (int t = 0; t < nk; t++) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    lds_barrier();  // stage t landed (everyone's DMA); every wave is past its reads of the other buffer
-    const unsigned char* sa = smem + (t & 1) * V_BUFBYTES;
-    const unsigned char* sb = sa + V_ABYTES;
-    if (t + 1 < nk) {
-      unsigned char* da = smem + ((t + 1) & 1) * V_BUFBYTES;
-      vstage_glds<TA>(A, p.lda, tm0, kbeg + (long long)(t + 1) * V_BK, da, tid);
-      vstage_glds<TB>(B, p.ldb, tn0, kbeg + (long long)(t + 1) * V_BK, da + V_ABYTES, tid);
+    unsigned char* s0 = smem + (t & 1) * V_BUFBYTES;         // stage t
+    unsigned char* s1 = smem + ((t + 1) & 1) * V_BUFBYTES;   // stage t + 1
+    half_step(s0, s0 + V_ABYTES, 1, fa, fb);                  // (t, 0) multiplies, (t, 1) is read
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // own DMA of stage t + 1
+    lds_barrier();                                            // everyone's; every wave has finished reading stage t
+    if (t + 2 < nk) {
+      vstage_glds<TA>(A, p.lda, tm0, kbeg + (long long)(t + 2) * V_BK, s0, tid);
+      vstage_glds<TB>(B, p.ldb, tn0, kbeg + (long long)(t + 2) * V_BK, s0 + V_ABYTES, tid);
     }
-#pragma unroll
-    for (int ks = 0; ks < 2; ks++) {
-      bf8v fa[4], fb[4];
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        fa[i] = TA ? vfrag_kmajor(sa, wm * 64 + i * 16, ks, lane) : vfrag_rowmajor(sa, wm * 64 + i * 16, ks, lane);
-        fb[i] = TB ? vfrag_kmajor(sb, wn * 64 + i * 16, ks, lane) : vfrag_rowmajor(sb, wn * 64 + i * 16, ks, lane);
-      }
-#pragma unroll
-      for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-    }
+    half_step(s1, s1 + V_ABYTES, 0, fa, fb);                  // (t, 1) multiplies, (t + 1, 0) is read (unused garbage after the last stage)
   }
 
   // ---- epilogue: four 64-row chunks through LDS -> whole 512-byte row segments (16-byte lanes)
@@ -204,6 +229,13 @@ bool pero_launch_gemm_v256(const GemmP& p0, long long batch, int k_split, bool t
     k_split = 1;
   }
   dim3 grid((unsigned)((p.M / V_BM) * (p.N / V_BN)), (unsigned)batch, (unsigned)k_split), block(1024);
+  int ks_xcd = 0;
+  const long long tiles = (p.M / V_BM) * (p.N / V_BN);
+  if (batch == 1 && k_split > 1 && (k_split == 2 || k_split == 4 || k_split % 8 == 0) && (tiles * k_split) % 8 == 0 &&
+      (k_split >= 8 || tiles % (8 / k_split) == 0)) {
+    ks_xcd = k_split;
+    grid = dim3((unsigned)(tiles * k_split), 1, 1);
+  }
 #define LAUNCH_V(TA_, TB_, OF_)                                                                                            \
   do {                                                                                                                     \
     static bool attr_set = false;                                                                                          \
@@ -211,7 +243,7 @@ bool pero_launch_gemm_v256(const GemmP& p0, long long batch, int k_split, bool t
       hipFuncSetAttribute((const void*)gemm_bf16_v256<TA_, TB_, OF_>, hipFuncAttributeMaxDynamicSharedMemorySize, V_LDS_BYTES); \
       attr_set = true;                                                                                                     \
     }                                                                                                                      \
-    hipLaunchKernelGGL((gemm_bf16_v256<TA_, TB_, OF_>), grid, block, V_LDS_BYTES, st, p);                                  \
+    hipLaunchKernelGGL((gemm_bf16_v256<TA_, TB_, OF_>), grid, block, V_LDS_BYTES, st, p, ks_xcd);                                  \
   } while (0)
   if (!ta && !tb) { if (out_f32) LAUNCH_V(false, false, true); else LAUNCH_V(false, false, false); }
   else if (!ta && tb) { if (out_f32) LAUNCH_V(false, true, true); else LAUNCH_V(false, true, false); }
