@@ -41,6 +41,9 @@ extern "C" {
 #define PERO_GEMM_TILE256 128    /* benchmarking: force the 256x256-tile bf16 kernel (when the shape allows) */
 #define PERO_GEMM_TILE_S 256     /* benchmarking: force the 128x128x32 four-workgroups-per-CU kernel */
 #define PERO_GEMM_TILE_V 512     /* prefer the 256x256x64 one-workgroup-per-CU kernel (whole GPU to itself: forward pass) */
+#define PERO_GEMM_COLSUM 1024   /* `bias` is an OUTPUT (f32 [N], accumulated atomically): column sums over the M rows of the
+                                 * stored result - the bias gradient of the Linear whose output gradient this product
+                                 * writes (replaces a separate pero_colsum pass over C).  No input bias in this mode. */
 #define PERO_GEMM_FORCE_GENERIC 32 /* testing: take the exact-f32 generic kernel even when the fast bf16 kernel applies */
 
 const char* pero_last_error(void);

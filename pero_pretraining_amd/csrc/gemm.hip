@@ -373,11 +373,32 @@ extern "C" int pero_set_option(const char* name, int value) {
   return PERO_E_INVALID;
 }
 
+static int gemm_dispatch(const void* A, const void* B, void* C, const float* bias, const void* residual, const void* gate,
+                         int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int64_t ldg,
+                         int64_t batch, int64_t batch_inner,
+                         int64_t sAo, int64_t sAi, int64_t sBo, int64_t sBi, int64_t sCo, int64_t sCi,
+                         float alpha, int flags, int k_split, int in_dtype, int out_dtype, void* stream, bool* colsum_fused);
+
 extern "C" int pero_gemm(const void* A, const void* B, void* C, const float* bias, const void* residual, const void* gate,
                          int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int64_t ldg,
                          int64_t batch, int64_t batch_inner,
                          int64_t sAo, int64_t sAi, int64_t sBo, int64_t sBi, int64_t sCo, int64_t sCi,
                          float alpha, int flags, int k_split, int in_dtype, int out_dtype, void* stream) {
+  bool fused = false;
+  if (flags & PERO_GEMM_COLSUM)
+    PERO_REQUIRE(bias && batch == 1 && !(flags & (PERO_GEMM_ATOMIC | PERO_GEMM_ACCUM)),
+                 "pero_gemm: PERO_GEMM_COLSUM needs the output pointer in `bias`, one problem, a stored result");
+  const int rc = gemm_dispatch(A, B, C, bias, residual, gate, M, N, K, lda, ldb, ldc, ldr, ldg, batch, batch_inner, sAo, sAi, sBo, sBi,
+                               sCo, sCi, alpha, flags, k_split, in_dtype, out_dtype, stream, &fused);
+  if (rc != PERO_OK || !(flags & PERO_GEMM_COLSUM) || fused) return rc;
+  return pero_colsum(C, (float*)bias, M, N, ldc, out_dtype, stream);  // kernels without the fused epilogue: a pass over C
+}
+
+static int gemm_dispatch(const void* A, const void* B, void* C, const float* bias, const void* residual, const void* gate,
+                         int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int64_t ldg,
+                         int64_t batch, int64_t batch_inner,
+                         int64_t sAo, int64_t sAi, int64_t sBo, int64_t sBi, int64_t sCo, int64_t sCi,
+                         float alpha, int flags, int k_split, int in_dtype, int out_dtype, void* stream, bool* colsum_fused) {
   PERO_REQUIRE(A && B && C, "pero_gemm: null operand");
   PERO_REQUIRE(M > 0 && N > 0 && K > 0 && batch > 0 && batch_inner > 0, "pero_gemm: bad sizes M=%lld N=%lld K=%lld batch=%lld",
                (long long)M, (long long)N, (long long)K, (long long)batch);
@@ -392,6 +413,11 @@ extern "C" int pero_gemm(const void* A, const void* B, void* C, const float* bia
   p.sAo = sAo; p.sAi = sAi; p.sBo = sBo; p.sBi = sBi; p.sCo = sCo; p.sCi = sCi;
   p.binner = (int)batch_inner; p.alpha = alpha; p.flags = flags; p.kchunk = K;
   hipStream_t st = (hipStream_t)stream;
+  // PERO_GEMM_COLSUM: only the r256 / v256 epilogues accumulate the column sums (`pc`); every other kernel gets `p`
+  // without the flag and without the (output) bias pointer, and pero_gemm runs pero_colsum over C afterwards.
+  const bool want_cs = flags & PERO_GEMM_COLSUM;
+  GemmP pc = p;
+  if (want_cs) { flags &= ~PERO_GEMM_COLSUM; p.flags = flags; p.bias = nullptr; }
 
   const int esz_o = out_dtype == PERO_F32 ? 4 : 2;
   bool fast = in_dtype == PERO_BF16 && !(flags & 32) && M % T_BM == 0 && N % T_BN == 0 && K % T_BK == 0 &&
@@ -404,6 +430,7 @@ extern "C" int pero_gemm(const void* A, const void* B, void* C, const float* bia
     else if (g_gemm_policy == 2) flags |= PERO_GEMM_TILE256;
     else if (g_gemm_policy == 3) flags |= PERO_GEMM_TILE_S;
     p.flags = flags;
+    pc.flags = flags | (want_cs ? PERO_GEMM_COLSUM : 0);
   }
   const bool forced0 = flags & (PERO_GEMM_TILE128 | PERO_GEMM_TILE256 | PERO_GEMM_TILE_S);
   if (fast) {
@@ -459,7 +486,8 @@ extern "C" int pero_gemm(const void* A, const void* B, void* C, const float* bia
       PERO_CHECK_LAUNCH("pero_gemm(w256)");
       return PERO_OK;
     }
-    if ((g_gemm_policy == 10 || g_gemm_policy == 12 || (g_gemm_policy == 11 && K >= 1024) || (g_gemm_policy == 0 && (flags & PERO_GEMM_TILE_V))) && !forced0 && !atomic && pero_launch_gemm_v256(p, batch, k_split, ta, tb, out_dtype == PERO_F32, st)) {
+    if ((g_gemm_policy == 10 || g_gemm_policy == 12 || (g_gemm_policy == 11 && K >= 1024) || (g_gemm_policy == 0 && (flags & PERO_GEMM_TILE_V))) && !forced0 && !atomic && pero_launch_gemm_v256(want_cs ? pc : p, batch, k_split, ta, tb, out_dtype == PERO_F32, st)) {
+      *colsum_fused = want_cs;
       PERO_CHECK_LAUNCH("pero_gemm(v256)");
       return PERO_OK;
     }
@@ -467,7 +495,8 @@ extern "C" int pero_gemm(const void* A, const void* B, void* C, const float* bia
       PERO_CHECK_LAUNCH("pero_gemm(bf16 q256)");
       return PERO_OK;
     }
-    if ((g_gemm_policy == 7 || g_gemm_policy == 0 || g_gemm_policy == 11) && !forced0 && !atomic && pero_launch_gemm_r256(p, batch, k_split, ta, tb, out_dtype == PERO_F32, st)) {
+    if ((g_gemm_policy == 7 || g_gemm_policy == 0 || g_gemm_policy == 11) && !forced0 && !atomic && pero_launch_gemm_r256(want_cs ? pc : p, batch, k_split, ta, tb, out_dtype == PERO_F32, st)) {
+      *colsum_fused = want_cs;
       PERO_CHECK_LAUNCH("pero_gemm(bf16 r256)");
       return PERO_OK;
     }

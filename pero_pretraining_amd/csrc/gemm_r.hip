@@ -150,8 +150,10 @@ __global__ __launch_bounds__(512, 4) void gemm_bf16_r256(GemmP p) {
   // direct 8-byte-per-lane epilogue's lower instruction count.
   const int c8 = (tid & 15) * 8;
   float bias[8];
+  const bool colsum = p.flags & PERO_GEMM_COLSUM;  // p.bias is then an OUTPUT (column sums of the stored result)
 #pragma unroll
-  for (int e = 0; e < 8; e++) bias[e] = p.bias ? p.bias[tn0 + c8 + e] : 0.f;
+  for (int e = 0; e < 8; e++) bias[e] = (p.bias && !colsum) ? p.bias[tn0 + c8 + e] : 0.f;
+  float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int half = 0; half < 4; half++) {
     __syncthreads();  // main-loop reads (half 0) / previous half's staging reads (half 1) are done
@@ -191,6 +193,10 @@ __global__ __launch_bounds__(512, 4) void gemm_bf16_r256(GemmP p) {
           if (!(__uint_as_float(w[e] & 0xffff0000u) > 0.f)) v[2 * e + 1] = 0.f;
         }
       }
+      if (colsum) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) cs[e] += v[e];
+      }
       if (OUTF32) {
         float* C = (float*)p.C + coff + grow * p.ldc + tn0 + c8;
         if (p.flags & PERO_GEMM_ATOMIC) {
@@ -210,6 +216,25 @@ __global__ __launch_bounds__(512, 4) void gemm_bf16_r256(GemmP p) {
         o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]); o.z = pack2bf(v[4], v[5]); o.w = pack2bf(v[6], v[7]);
         *(uint4*)((bf16raw*)p.C + coff + grow * p.ldc + tn0 + c8) = o;
       }
+    }
+  }
+  if (colsum) {
+    // tile column sums: registers (8 rows per thread) -> lanes sharing a column group (xor 16, 32) -> LDS over the 8 waves
+    // -> one atomic per column and tile
+#pragma unroll
+    for (int e = 0; e < 8; e++) { cs[e] += __shfl_xor(cs[e], 16, 64); cs[e] += __shfl_xor(cs[e], 32, 64); }
+    __syncthreads();
+    float* red = (float*)smem;
+    if (lane < 16) {
+#pragma unroll
+      for (int e = 0; e < 8; e++) red[wave * 128 + lane * 8 + e] = cs[e];
+    }
+    __syncthreads();
+    if (tid < 128) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; w++) t += red[w * 128 + tid];
+      atomicAdd((float*)p.bias + tn0 + tid, t);
     }
   }
 }

@@ -137,8 +137,10 @@ __global__ __launch_bounds__(1024, 4) void gemm_bf16_v256(GemmP p, int ks_xcd) {
   // ---- epilogue: four 64-row chunks through LDS -> whole 512-byte row segments (16-byte lanes)
   const int c8 = (tid & 31) * 8;
   float bias[8];
+  const bool colsum = p.flags & PERO_GEMM_COLSUM;  // p.bias is then an OUTPUT (column sums of the stored result)
 #pragma unroll
-  for (int e = 0; e < 8; e++) bias[e] = p.bias ? p.bias[tn0 + c8 + e] : 0.f;
+  for (int e = 0; e < 8; e++) bias[e] = (p.bias && !colsum) ? p.bias[tn0 + c8 + e] : 0.f;
+  float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int qq = 0; qq < 4; qq++) {
     lds_barrier();
@@ -193,6 +195,10 @@ __global__ __launch_bounds__(1024, 4) void gemm_bf16_v256(GemmP p, int ks_xcd) {
           if (!(__uint_as_float(w[e] & 0xffff0000u) > 0.f)) v[2 * e + 1] = 0.f;
         }
       }
+      if (colsum) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) cs[e] += v[e];
+      }
       if (OUTF32) {
         float* C = (float*)p.C + coff + grow * p.ldc + tn0 + c8;
         if (p.flags & PERO_GEMM_ATOMIC) {
@@ -212,6 +218,24 @@ __global__ __launch_bounds__(1024, 4) void gemm_bf16_v256(GemmP p, int ks_xcd) {
         o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]); o.z = pack2bf(v[4], v[5]); o.w = pack2bf(v[6], v[7]);
         *(uint4*)((bf16raw*)p.C + coff + grow * p.ldc + tn0 + c8) = o;
       }
+    }
+  }
+  if (colsum) {
+    // tile column sums: registers (8 rows per thread) -> lane ^ 32 (the other row of the wave) -> LDS over the 16 waves
+#pragma unroll
+    for (int e = 0; e < 8; e++) cs[e] += __shfl_xor(cs[e], 32, 64);
+    lds_barrier();
+    float* red = (float*)smem;
+    if (lane < 32) {
+#pragma unroll
+      for (int e = 0; e < 8; e++) red[wave * 256 + lane * 8 + e] = cs[e];
+    }
+    lds_barrier();
+    if (tid < 256) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < 16; w++) t += red[w * 256 + tid];
+      atomicAdd((float*)p.bias + tn0 + tid, t);
     }
   }
 }

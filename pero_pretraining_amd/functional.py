@@ -41,6 +41,7 @@ def linear_fwd(x, w, b, dtype, residual=None, relu=False, out_dtype=None):
                     out_dtype=out_dtype, extra_flags=FWD_TILE_FLAGS)
 
 
+FUSE_BIAS_GRAD = True  # bias gradients that are column sums of a dX product's output come out of that product's epilogue
 SIDE_STREAM_DW = True  # weight / bias gradients on a second HIP stream (they are off the backward critical path)
 SIDE_STREAMS = 2       # side streams used round-robin (2 streams + split-K aiming at 256 work items: -1.7 % in-step)
 _side_streams = {}
@@ -99,8 +100,10 @@ class SideStream:
         self.keep = []
 
 
-def linear_bwd(dy, x, w, b, dtype, need_dx=True, gate=None, residual=None, bias_grad_done=False, side=None):
-    """dy (M,N), x (M,K), w (N,K).  Accumulates dW (+db) into .grad; returns dx = dy @ W (+residual)(*gate>0)."""
+def linear_bwd(dy, x, w, b, dtype, need_dx=True, gate=None, residual=None, bias_grad_done=False, side=None, dx_colsum_into=None):
+    """dy (M,N), x (M,K), w (N,K).  Accumulates dW (+db) into .grad; returns dx = dy @ W (+residual)(*gate>0).
+    dx_colsum_into: f32 [K] that receives the column sums of dx (the bias gradient of the Linear that produced x), fused
+    into the dX product's epilogue."""
     def grads():
         if w.requires_grad:
             ops.gemm(dy, x, out=ensure_grad(w).view(w.shape[0], -1), trans_a=True, trans_b=True, atomic=True, k_split=0)
@@ -115,7 +118,8 @@ def linear_bwd(dy, x, w, b, dtype, need_dx=True, gate=None, residual=None, bias_
         grads()
     if not need_dx:
         return None
-    return ops.gemm(dy, lowp.weight(w, dtype).view(w.shape[0], -1), trans_b=True, residual=residual, gate=gate)
+    return ops.gemm(dy, lowp.weight(w, dtype).view(w.shape[0], -1), trans_b=True, residual=residual, gate=gate,
+                    colsum_into=dx_colsum_into)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -182,8 +186,11 @@ def layer_bwd(dt2, L, saved, n, s, h, dtype, side=None):
     # LN2 (its dx column sums are linear2's bias gradient)
     dy2 = ops.layernorm_bwd(dt2, y2, mean2, rstd2, L.norm2.weight.detach(), ensure_grad(L.norm2.weight),
                             ensure_grad(L.norm2.bias), ensure_grad(L.linear2.bias))
-    dpre1 = linear_bwd(dy2, hdn, L.linear2.weight, L.linear2.bias, dtype, gate=hdn, bias_grad_done=True, side=side)
-    dt1 = linear_bwd(dpre1, t1, L.linear1.weight, L.linear1.bias, dtype, residual=dy2, side=side)
+    # linear1's bias gradient = column sums of dpre1: accumulated by the epilogue of the product that writes dpre1
+    fuse_b1 = FUSE_BIAS_GRAD and dtype == torch.bfloat16 and L.linear1.bias is not None and L.linear1.bias.requires_grad
+    dpre1 = linear_bwd(dy2, hdn, L.linear2.weight, L.linear2.bias, dtype, gate=hdn, bias_grad_done=True, side=side,
+                       dx_colsum_into=ensure_grad(L.linear1.bias) if fuse_b1 else None)
+    dt1 = linear_bwd(dpre1, t1, L.linear1.weight, L.linear1.bias, dtype, residual=dy2, side=side, bias_grad_done=fuse_b1)
     dy1 = ops.layernorm_bwd(dt1, y1, mean1, rstd1, L.norm1.weight.detach(), ensure_grad(L.norm1.weight),
                             ensure_grad(L.norm1.bias), ensure_grad(at.out_proj.bias))
     da = linear_bwd(dy1, a, at.out_proj.weight, at.out_proj.bias, dtype, bias_grad_done=True, side=side)

@@ -3,7 +3,7 @@ current HIP stream; all arithmetic happens in the hand-written kernels.  No CPU 
 import torch
 
 from . import _lib
-from ._lib import (GEMM_ACCUM, GEMM_ATOMIC, GEMM_FORCE_GENERIC, GEMM_RELU, GEMM_TRANS_A, GEMM_TRANS_B,
+from ._lib import (GEMM_ACCUM, GEMM_ATOMIC, GEMM_COLSUM, GEMM_FORCE_GENERIC, GEMM_RELU, GEMM_TRANS_A, GEMM_TRANS_B,
                    PERO_BF16, PERO_F32, call)
 
 
@@ -55,9 +55,11 @@ def gemm_raw(A, B, C, M, N, K, lda, ldb, ldc, *, bias=None, residual=None, gate=
 
 
 def gemm(a, b, out=None, *, bias=None, residual=None, gate=None, trans_a=False, trans_b=False, relu=False,
-         alpha=1.0, out_dtype=None, atomic=False, accum=False, k_split=1, force_generic=False, extra_flags=0):
+         alpha=1.0, out_dtype=None, atomic=False, accum=False, k_split=1, force_generic=False, extra_flags=0,
+         colsum_into=None):
     """out[M,N] = alpha * op(a) @ op(b)^T ...   a: [M,K] ([K,M] if trans_a); b: [N,K] ([K,N] if trans_b).
-    Row-strided 2-D views are fine (unit stride in the last dim)."""
+    Row-strided 2-D views are fine (unit stride in the last dim).  colsum_into (f32 [N]): the column sums of the stored
+    result are accumulated into it (PERO_GEMM_COLSUM; no input bias in that mode)."""
     assert a.dim() == 2 and b.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1
     M, K = (a.shape[1], a.shape[0]) if trans_a else a.shape
     N, Kb = (b.shape[1], b.shape[0]) if trans_b else b.shape
@@ -67,6 +69,9 @@ def gemm(a, b, out=None, *, bias=None, residual=None, gate=None, trans_a=False, 
     assert out.shape == (M, N) and out.stride(1) == 1
     flags = (GEMM_RELU if relu else 0) | (GEMM_TRANS_A if trans_a else 0) | (GEMM_TRANS_B if trans_b else 0) | \
         (GEMM_ATOMIC if atomic else 0) | (GEMM_ACCUM if accum else 0) | (GEMM_FORCE_GENERIC if force_generic else 0) | extra_flags
+    if colsum_into is not None:
+        assert bias is None and colsum_into.dtype == torch.float32 and colsum_into.numel() == N
+        bias, flags = colsum_into, flags | GEMM_COLSUM
     gemm_raw(a, b, out, M, N, K, a.stride(0), b.stride(0), out.stride(0), bias=bias, residual=residual, gate=gate,
              ldr=residual.stride(0) if residual is not None else 0, ldg=gate.stride(0) if gate is not None else 0,
              alpha=alpha, flags=flags, k_split=k_split)

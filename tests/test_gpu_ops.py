@@ -452,3 +452,22 @@ def test_gather_scatter(ops):
         ref = src.clone().float()
         ref[index] += src[index].float()
         assert torch.equal(dst.cpu(), ref.to(dtype))
+
+
+@pytest.mark.parametrize("M,N,K", [(512, 256, 128), (256, 128, 64), (192, 136, 72)])
+@pytest.mark.parametrize("with_gate", [False, True])
+def test_gemm_fused_column_sums(M, N, K, with_gate):
+    """PERO_GEMM_COLSUM: the bias gradient of the upstream Linear out of the dX product's epilogue (tile kernels) or the
+    library's fallback pass (other shapes); accumulates into the output vector."""
+    from pero_pretraining_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    dy = (torch.randn(M, K, device="cuda", generator=g) * 0.5).bfloat16()
+    w = (torch.randn(K, N, device="cuda", generator=g) * 0.5).bfloat16()
+    gate = (torch.randn(M, N, device="cuda", generator=g)).bfloat16() if with_gate else None
+    acc = torch.full((N,), 3.0, device="cuda")
+    out = ops.gemm(dy, w, trans_b=True, gate=gate, colsum_into=acc)
+    ref = ops.gemm(dy, w, trans_b=True, gate=gate)
+    assert torch.equal(out, ref)                                  # the stored result is unchanged by the fused reduction
+    want = 3.0 + ref.float().sum(0)
+    err = (acc - want).abs().max().item()
+    assert err <= 2e-2 * max(1.0, want.abs().max().item()), err   # f32 sums of pre-rounding values vs sums of bf16 values
