@@ -458,6 +458,22 @@ static int gemm_dispatch(const void* A, const void* B, void* C, const float* bia
     } else if (k_split < 1) {
       k_split = 1;
     }
+    if (g_gemm_policy == 14 && atomic && !forced0 && out_dtype == PERO_F32 && M % 256 == 0) {  // experiment: 256x128x32 split-K tiles
+      long long ks2 = k_split_req;
+      const long long tr = (M / 256) * (N / 128);
+      if (ks2 == 0) {
+        ks2 = (g_splitk_items + tr - 1) / tr;
+        if (ks2 >= 8) ks2 = ((ks2 + 7) / 8) * 8;
+        else if (ks2 > 4) ks2 = 8;
+        else if (ks2 == 3) ks2 = 4;
+        if (ks2 > K / 256) ks2 = K / 256;
+        if (ks2 < 1) ks2 = 1;
+      }
+      if (pero_launch_gemm_r256(p, batch, (int)ks2, ta, tb, true, st)) {
+        PERO_CHECK_LAUNCH("pero_gemm(r256 split-K)");
+        return PERO_OK;
+      }
+    }
     if (g_gemm_policy == 13 && atomic && can256 && !forced0 && out_dtype == PERO_F32) {  // experiment: 256x256x64 split-K tiles
       long long ks2 = k_split_req;
       if (ks2 == 0) {

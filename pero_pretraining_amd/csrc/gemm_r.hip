@@ -71,22 +71,30 @@ __device__ __forceinline__ void rstage_glds(const bf16raw* X, long long ld, long
 }
 
 template <bool TA, bool TB, bool OUTF32>
-__global__ __launch_bounds__(512, 4) void gemm_bf16_r256(GemmP p) {
+__global__ __launch_bounds__(512, 4) void gemm_bf16_r256(GemmP p, int ks_xcd) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int ntn = (int)(p.N / R_BN);
   const int nt = (int)(p.M / R_BM) * ntn;
   const int bid = blockIdx.x;
-  const int q = nt >> 3, r8 = nt & 7, xcd = bid & 7, loc = bid >> 3;
-  const int id = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + loc;
+  int id, zslice;
+  if (ks_xcd > 0) {  // split-K: one k-slice per XCD, all of its tiles on that XCD's L2 (as gemm_bf16_o128)
+    const int xcd = bid & 7, r = bid >> 3;
+    if (ks_xcd >= 8) { const int per = ks_xcd >> 3; zslice = xcd * per + (r % per); id = r / per; }
+    else { zslice = xcd % ks_xcd; id = r * (8 / ks_xcd) + xcd / ks_xcd; }
+  } else {
+    const int q = nt >> 3, r8 = nt & 7, xcd = bid & 7, loc = bid >> 3;
+    id = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + loc;
+    zslice = blockIdx.z;
+  }
   const long long tm0 = (long long)(id / ntn) * R_BM, tn0 = (long long)(id % ntn) * R_BN;
   const int b = blockIdx.y;
   const long long bo = b / p.binner, bi = b % p.binner;
   const bf16raw* A = (const bf16raw*)p.A + bo * p.sAo + bi * p.sAi;
   const bf16raw* B = (const bf16raw*)p.B + bo * p.sBo + bi * p.sBi;
   const long long coff = bo * p.sCo + bi * p.sCi;
-  const long long kbeg = (long long)blockIdx.z * p.kchunk;
+  const long long kbeg = (long long)zslice * p.kchunk;
   long long kend = kbeg + p.kchunk;
   if (kend > p.K) kend = p.K;
   const int nk = (int)((kend - kbeg) / R_BK);
@@ -165,6 +173,20 @@ __global__ __launch_bounds__(512, 4) void gemm_bf16_r256(GemmP p) {
           *(f4v*)(smem + (i * 16 + (lane & 15)) * R_EPI_PITCH + (wn * 64 + j * 16 + (lane >> 4) * 4) * 4) = acc[i][j];
     }
     __syncthreads();
+    if (OUTF32 && (p.flags & PERO_GEMM_ATOMIC)) {
+      // split-K partial sums: one wave instruction adds 64 consecutive floats of a row (256 contiguous bytes)
+#pragma unroll
+      for (int rr = 0; rr < 8; rr++) {
+        const int row = wave * 8 + rr;
+        float* C = (float*)p.C + coff + (tm0 + half * 64 + row) * p.ldc + tn0;
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+          const int col = e * 64 + lane;
+          atomicAdd(C + col, *(const float*)(smem + row * R_EPI_PITCH + col * 4) * p.alpha);
+        }
+      }
+      continue;
+    }
 #pragma unroll
     for (int rr = 0; rr < 2; rr++) {
       const int row = (tid >> 4) + 32 * rr;
@@ -252,6 +274,13 @@ bool pero_launch_gemm_r256(const GemmP& p0, long long batch, int k_split, bool t
     k_split = 1;
   }
   dim3 grid((unsigned)((p.M / R_BM) * (p.N / R_BN)), (unsigned)batch, (unsigned)k_split), block(512);
+  int ks_xcd = 0;
+  const long long tiles = (p.M / R_BM) * (p.N / R_BN);
+  if (batch == 1 && k_split > 1 && (k_split == 2 || k_split == 4 || k_split % 8 == 0) && (tiles * k_split) % 8 == 0 &&
+      (k_split >= 8 || tiles % (8 / k_split) == 0)) {
+    ks_xcd = k_split;
+    grid = dim3((unsigned)(tiles * k_split), 1, 1);
+  }
 #define LAUNCH_R(TA_, TB_, OF_)                                                                                            \
   do {                                                                                                                     \
     static bool attr_set = false;                                                                                          \
@@ -259,7 +288,7 @@ bool pero_launch_gemm_r256(const GemmP& p0, long long batch, int k_split, bool t
       hipFuncSetAttribute((const void*)gemm_bf16_r256<TA_, TB_, OF_>, hipFuncAttributeMaxDynamicSharedMemorySize, R_LDS_BYTES); \
       attr_set = true;                                                                                                     \
     }                                                                                                                      \
-    hipLaunchKernelGGL((gemm_bf16_r256<TA_, TB_, OF_>), grid, block, R_LDS_BYTES, st, p);                                  \
+    hipLaunchKernelGGL((gemm_bf16_r256<TA_, TB_, OF_>), grid, block, R_LDS_BYTES, st, p, ks_xcd);                                  \
   } while (0)
   if (!ta && !tb) { if (out_f32) LAUNCH_R(false, false, true); else LAUNCH_R(false, false, false); }
   else if (!ta && tb) { if (out_f32) LAUNCH_R(false, true, true); else LAUNCH_R(false, true, false); }
