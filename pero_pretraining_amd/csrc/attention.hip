@@ -15,6 +15,9 @@
 // swizzled in 64-byte blocks for conflict-free transposed reads.  2 workgroups per CU (64 KiB LDS each).
 #include "common.hpp"
 
+#define AT_HALF_BYTES 16384   // 64 rows x 256 B
+#define AT_SUB_BYTES 8192     // 32 rows x 256 B
+#define AT_DKV2_LDS (4 * AT_SUB_BYTES + 128 * 128 * 2 + 512)  // Q / dO stages x 2, V tile, row statistics x 2
 #define AT_TILE_BYTES (128 * 128 * 2)  // 32 KiB: 128 keys x 128 head-dim bf16
 
 // piece p (0..31) of a 128x128 bf16 tile = rows 4p..4p+3 (1 KiB); lane -> (row, 16-byte slot)
@@ -53,6 +56,19 @@ __device__ __forceinline__ bf8v pack8(const f16v& a, int s) {
   return __builtin_bit_cast(bf8v, u);
 }
 
+// Workgroup -> ((line, head), block) so that the blocks of one (line, head) - which read the same K / V (or Q / dO) rows -
+// run on ONE XCD, next to each other in dispatch order (hardware places workgroup b on XCD b & 7): the second reader then
+// hits that XCD's L2 instead of fetching the rows again through the fabric.  Needs (lines x heads) % 8 == 0.
+__device__ __forceinline__ void attn_block_map(int bid, int nblk, int nlh, int& lh, int& blk) {
+  if ((nlh & 7) == 0) {
+    const int xcd = bid & 7, u = bid >> 3;
+    lh = (u / nblk) * 8 + xcd;
+    blk = u % nblk;
+  } else {
+    lh = bid / nblk;
+    blk = bid % nblk;
+  }
+}
 // hpb = heads per workgroup: the (head, key tile) pairs of `hpb` heads of one line are walked as ONE stream, so the
 // LDS-DMA of the next head's first K / V tile and the global loads of its Q rows run under the current head's last
 // tile.  At S = 256 a (line, head, 128 queries) unit is only two key tiles: measured 439 TFLOP/s against 855 at S = 2048
@@ -63,7 +79,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_k(const bf16raw* qkv, bf16raw
   unsigned char* vimg = smem + AT_TILE_BYTES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h5 = lane >> 5, r = lane & 31;
   const int nqb = S >> 7, ngrp = nh / hpb;
-  const int qb = blockIdx.x % nqb, lg = blockIdx.x / nqb;
+  int lg, qb;
+  attn_block_map(blockIdx.x, nqb, gridDim.x / nqb, lg, qb);
   const int line = lg / ngrp, head0 = (lg % ngrp) * hpb;
   const long long d = (long long)nh * 128, ld = 3 * d;
   const bf16raw* lbase = qkv + (long long)line * S * ld;  // + head * 128 : q ; + d : k ; + 2d : v
@@ -241,6 +258,28 @@ __device__ __forceinline__ void attn_glds_img(const bf16raw* g, long long ld, un
                                      (__attribute__((address_space(3))) void*)(lds + p * 1024), 16, 0, 0);
   }
 }
+// 64-row half image (16 KiB): same layout, pieces 0..15
+__device__ __forceinline__ void attn_glds_half(const bf16raw* g, long long ld, unsigned char* lds, int wave, int lane) {
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int p = wave + 4 * i;
+    const int row = 4 * p + (lane >> 4), slot = lane & 15;
+    const int chunk = slot ^ img_f(row);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + (long long)row * ld + chunk * 8),
+                                     (__attribute__((address_space(3))) void*)(lds + p * 1024), 16, 0, 0);
+  }
+}
+// 32-row stage (8 KiB): pieces 0..7
+__device__ __forceinline__ void attn_glds_sub(const bf16raw* g, long long ld, unsigned char* lds, int wave, int lane) {
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    const int p = wave + 4 * i;
+    const int row = 4 * p + (lane >> 4), slot = lane & 15;
+    const int chunk = slot ^ img_f(row);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + (long long)row * ld + chunk * 8),
+                                     (__attribute__((address_space(3))) void*)(lds + p * 1024), 16, 0, 0);
+  }
+}
 // A operand, row-wise: lane holds M[row][16*ks + 8*h5 .. +8]
 __device__ __forceinline__ bf8v img_row_frag(const unsigned char* img, int row, int ks, int h5) {
   return *(const bf8v*)(img + row * 256 + (((2 * ks + h5) ^ img_f(row)) << 4));
@@ -263,11 +302,10 @@ __device__ __forceinline__ bf8v img_tr_frag(const unsigned char* img, int rb, in
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_k(const bf16raw* qkv, const bf16raw* out, const bf16raw* dout, const float* lse2,
                                                         float* dvec, bf16raw* dqkv, int S, int nh, float c, float scale) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* kimg = smem;
-  unsigned char* vimg = smem + AT_TILE_BYTES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h5 = lane >> 5, r = lane & 31;
   const int nqb = S >> 7;
-  const int qb = blockIdx.x % nqb, lh = blockIdx.x / nqb;
+  int lh, qb;
+  attn_block_map(blockIdx.x, nqb, gridDim.x / nqb, lh, qb);
   const int line = lh / nh, head = lh % nh;
   const long long d = (long long)nh * 128, ld = 3 * d;
   const bf16raw* base = qkv + (long long)line * S * ld + head * 128;
@@ -275,8 +313,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_k(const bf16raw* qkv, cons
   const bf16raw* Vg = base + 2 * d;
   const int q = qb * 128 + wave * 32 + r;
 
-  attn_glds_img(Kg, ld, kimg, wave, lane);
-  attn_glds_img(Vg, ld, vimg, wave, lane);
+  // K / V are staged in 64-key HALF tiles, double-buffered (2 x (16 + 16) KiB = the LDS of one 128-key tile pair before):
+  // the DMA of the next half runs under the current half's 48 MFMAs per wave.  With whole 128-key tiles and one buffer
+  // the DMA was issued after the tile's last read and waited for at the top of the next one - its whole latency exposed
+  // once per key tile, twice per workgroup at S = 256.
+  attn_glds_half(Kg, ld, smem, wave, lane);
+  attn_glds_half(Vg, ld, smem + AT_HALF_BYTES, wave, lane);
 
   bf8v qf[8], gf[8];
   float dsum = 0.f;
@@ -300,12 +342,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_k(const bf16raw* qkv, cons
   f16v dq[4];
 #pragma unroll
   for (int t = 0; t < 4; t++) dq[t] = (f16v){0};
-  const int nkt = S >> 7;
-  for (int kt = 0; kt < nkt; kt++) {
+  const int nhalf = S >> 6;
+  for (int hk = 0; hk < nhalf; hk++) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    __syncthreads();  // half hk landed; every wave is done with the other buffer
+    const unsigned char* kimg = smem + (hk & 1) * 2 * AT_HALF_BYTES;
+    const unsigned char* vimg = kimg + AT_HALF_BYTES;
+    if (hk + 1 < nhalf) {
+      unsigned char* nb = smem + ((hk + 1) & 1) * 2 * AT_HALF_BYTES;
+      attn_glds_half(Kg + (long long)(hk + 1) * 64 * ld, ld, nb, wave, lane);
+      attn_glds_half(Vg + (long long)(hk + 1) * 64 * ld, ld, nb + AT_HALF_BYTES, wave, lane);
+    }
 #pragma unroll
-    for (int t = 0; t < 4; t++) {  // 32-key sub-tile
+    for (int t = 0; t < 2; t++) {  // 32-key sub-tile
       f16v s = {0}, dp = {0};
 #pragma unroll
       for (int ks = 0; ks < 8; ks++) {
@@ -325,11 +374,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_k(const bf16raw* qkv, cons
           dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_tr_frag(kimg, t * 32 + sub * 16, dt, lane), dsf, dq[dt], 0, 0, 0);
       }
     }
-    if (kt + 1 < nkt) {
-      __syncthreads();
-      attn_glds_img(Kg + (long long)(kt + 1) * 128 * ld, ld, kimg, wave, lane);
-      attn_glds_img(Vg + (long long)(kt + 1) * 128 * ld, ld, vimg, wave, lane);
-    }
   }
   bf16raw* orow = dqkv + ((long long)line * S + q) * ld + head * 128;
 #pragma unroll
@@ -343,92 +387,98 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_k(const bf16raw* qkv, cons
     }
 }
 
-// ROLE 0: dV only (S, P, dV^T += dO^T P).  ROLE 1: dK only (S, P, dP, dS, dK^T += Q^T dS).  Holding both
-// accumulator sets plus both register-resident key operands in one wave needs > 256 VGPRs (spills), so the two
-// gradients are separate launches of one template.
-template <int ROLE>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_k(const bf16raw* qkv, const bf16raw* dout, const float* lse2, const float* dvec,
-                                                         bf16raw* dqkv, int S, int nh, float c, float scale) {
+// dK and dV in ONE pass (4 products: S, dP, dV^T += dO^T P, dK^T += Q^T dS; key on the lane).  The two-launch form read
+// Q, dO and K twice and computed S twice (605 MB and 5 products per layer at S = 256, d = 512); both launches were HBM-bound
+// to about half (row / tile reads of 256 KiB per workgroup for ~2.6 us of MFMA work).  What made the single pass spill before
+// was register-resident V next to register-resident K and two accumulator sets; here the workgroup's 128 x 128 V tile
+// lives in LDS (read as the B operand of dP) and Q / dO arrive in 32-query stages (8 + 8 KiB, double-buffered), so the
+// footprint stays at 64.5 KiB = two workgroups per CU.
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv2_k(const bf16raw* qkv, const bf16raw* dout, const float* lse2, const float* dvec,
+                                                          bf16raw* dqkv, int S, int nh, float c, float scale) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* qimg = smem;
-  unsigned char* gimg = smem + AT_TILE_BYTES;
-  float* lds_l = (float*)(smem + 2 * AT_TILE_BYTES);  // 128 lse2 + 128 D values of the current query tile
-  float* lds_d = lds_l + 128;
+  unsigned char* vimg = smem + 4 * AT_SUB_BYTES;
+  float* lds_ld = (float*)(smem + 4 * AT_SUB_BYTES + AT_TILE_BYTES);  // [2 buffers][32 lse2 | 32 D]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h5 = lane >> 5, r = lane & 31;
   const int nkb = S >> 7;
-  const int kb = blockIdx.x % nkb, lh = blockIdx.x / nkb;
+  int lh, kb;
+  attn_block_map(blockIdx.x, nkb, gridDim.x / nkb, lh, kb);
   const int line = lh / nh, head = lh % nh;
   const long long d = (long long)nh * 128, ld = 3 * d;
   const bf16raw* base = qkv + (long long)line * S * ld + head * 128;
   const bf16raw* Gg = dout + (long long)line * S * d + head * 128;
   const int key = kb * 128 + wave * 32 + r;
+  const float* stat = (tid < 32 ? lse2 : dvec) + (long long)lh * S + (tid & 31);  // threads 0-31: lse2, 32-63: D
 
-  attn_glds_img(base, ld, qimg, wave, lane);
-  attn_glds_img(Gg, d, gimg, wave, lane);
-  if (tid < 128) lds_l[tid] = lse2[(long long)lh * S + tid];
-  else lds_d[tid - 128] = dvec[(long long)lh * S + tid - 128];
+  if (tid < 64) lds_ld[tid] = stat[0];
+  attn_glds_img(base + 2 * d + (long long)kb * 128 * ld, ld, vimg, wave, lane);  // this workgroup's V tile, resident
+  attn_glds_sub(base, ld, smem, wave, lane);
+  attn_glds_sub(Gg, d, smem + AT_SUB_BYTES, wave, lane);
 
-  bf8v kf[8], vf[8];
+  bf8v kf[8];
   {
     const bf16raw* krow = base + d + (long long)key * ld + 8 * h5;
-    const bf16raw* vrow = base + 2 * d + (long long)key * ld + 8 * h5;
+#pragma unroll
+    for (int ks = 0; ks < 8; ks++) kf[ks] = *(const bf8v*)(krow + 16 * ks);
+  }
+  f16v dv[4], dk[4];  // dV^T, dK^T: 32 d x 32 keys per tile, key on the lane
+#pragma unroll
+  for (int t = 0; t < 4; t++) { dv[t] = (f16v){0}; dk[t] = (f16v){0}; }
+  const int nsub = S >> 5;
+  for (int sq = 0; sq < nsub; sq++) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // stage sq (Q / dO rows + statistics) landed; every wave is done with the other buffers
+    const unsigned char* qimg = smem + (sq & 1) * 2 * AT_SUB_BYTES;
+    const unsigned char* gimg = qimg + AT_SUB_BYTES;
+    const float* lds_l = lds_ld + (sq & 1) * 64;
+    const float* lds_d = lds_l + 32;
+    float nstat = 0.f;
+    if (sq + 1 < nsub) {
+      if (tid < 64) nstat = stat[(sq + 1) * 32];  // before the DMA: vmcnt is in-order
+      unsigned char* nb = smem + ((sq + 1) & 1) * 2 * AT_SUB_BYTES;
+      attn_glds_sub(base + (long long)(sq + 1) * 32 * ld, ld, nb, wave, lane);
+      attn_glds_sub(Gg + (long long)(sq + 1) * 32 * d, d, nb + AT_SUB_BYTES, wave, lane);
+    }
+    // rows q = (e&3) + 8(e>>2) + 4*h5 of the 32-query stage on the registers, key on the lane
+    f16v s = {0}, dp = {0};
 #pragma unroll
     for (int ks = 0; ks < 8; ks++) {
-      kf[ks] = *(const bf8v*)(krow + 16 * ks);
-      if (ROLE == 1) vf[ks] = *(const bf8v*)(vrow + 16 * ks);
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_row_frag(qimg, r, ks, h5), kf[ks], s, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_row_frag(gimg, r, ks, h5), img_row_frag(vimg, wave * 32 + r, ks, h5), dp, 0, 0, 0);
     }
+#pragma unroll
+    for (int g4 = 0; g4 < 4; g4++) {
+      const f4v l4 = *(const f4v*)(lds_l + 8 * g4 + 4 * h5);
+      const f4v d4 = *(const f4v*)(lds_d + 8 * g4 + 4 * h5);
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const float p = __builtin_amdgcn_exp2f(fmaf(s[4 * g4 + e], c, -l4[e]));
+        s[4 * g4 + e] = p;                                         // P
+        dp[4 * g4 + e] = p * (dp[4 * g4 + e] - d4[e]) * scale;     // dS
+      }
+    }
+#pragma unroll
+    for (int sub = 0; sub < 2; sub++) {
+      const bf8v pf = pack8(s, sub), dsf = pack8(dp, sub);
+#pragma unroll
+      for (int dt = 0; dt < 4; dt++) {
+        dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_tr_frag(gimg, sub * 16, dt, lane), pf, dv[dt], 0, 0, 0);   // dV^T += dO^T P
+        dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_tr_frag(qimg, sub * 16, dt, lane), dsf, dk[dt], 0, 0, 0);  // dK^T += Q^T dS
+      }
+    }
+    if (sq + 1 < nsub && tid < 64) lds_ld[((sq + 1) & 1) * 64 + tid] = nstat;  // visible after the next barrier
   }
-  f16v acc[4];  // dV^T (ROLE 0) or dK^T (ROLE 1): 32 d x 32 keys per tile, key on the lane
-#pragma unroll
-  for (int t = 0; t < 4; t++) acc[t] = (f16v){0};
-  const int nqt = S >> 7;
-  for (int qt = 0; qt < nqt; qt++) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-#pragma unroll
-    for (int t = 0; t < 4; t++) {  // 32-query sub-tile: rows q = t*32 + (e&3) + 8(e>>2) + 4*h5 on the registers
-      f16v s = {0}, dp = {0};
-#pragma unroll
-      for (int ks = 0; ks < 8; ks++) {
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_row_frag(qimg, t * 32 + r, ks, h5), kf[ks], s, 0, 0, 0);
-        if (ROLE == 1) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_row_frag(gimg, t * 32 + r, ks, h5), vf[ks], dp, 0, 0, 0);
-      }
-#pragma unroll
-      for (int g4 = 0; g4 < 4; g4++) {
-        const f4v l4 = *(const f4v*)(lds_l + t * 32 + 8 * g4 + 4 * h5);
-        const f4v d4 = *(const f4v*)(lds_d + t * 32 + 8 * g4 + 4 * h5);
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-          const float p = __builtin_amdgcn_exp2f(fmaf(s[4 * g4 + e], c, -l4[e]));
-          s[4 * g4 + e] = ROLE == 0 ? p : p * (dp[4 * g4 + e] - d4[e]) * scale;  // P or dS
-        }
-      }
-      const unsigned char* timg = ROLE == 0 ? gimg : qimg;  // dV^T += dO^T P ; dK^T += Q^T dS
-#pragma unroll
-      for (int sub = 0; sub < 2; sub++) {
-        const bf8v pf = pack8(s, sub);
-#pragma unroll
-        for (int dt = 0; dt < 4; dt++)
-          acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_tr_frag(timg, t * 32 + sub * 16, dt, lane), pf, acc[dt], 0, 0, 0);
-      }
-    }
-    if (qt + 1 < nqt) {
-      __syncthreads();
-      attn_glds_img(base + (long long)(qt + 1) * 128 * ld, ld, qimg, wave, lane);
-      attn_glds_img(Gg + (long long)(qt + 1) * 128 * d, d, gimg, wave, lane);
-      if (tid < 128) lds_l[tid] = lse2[(long long)lh * S + (qt + 1) * 128 + tid];
-      else lds_d[tid - 128] = dvec[(long long)lh * S + (qt + 1) * 128 + tid - 128];
-    }
-  }
-  bf16raw* orow = dqkv + ((long long)line * S + key) * ld + (ROLE == 0 ? 2 * d : d) + head * 128;
+  bf16raw* krow_o = dqkv + ((long long)line * S + key) * ld + d + head * 128;
 #pragma unroll
   for (int dt = 0; dt < 4; dt++)
 #pragma unroll
     for (int g4 = 0; g4 < 4; g4++) {
       uint2 w;
-      w.x = pack2bf(acc[dt][4 * g4 + 0], acc[dt][4 * g4 + 1]);
-      w.y = pack2bf(acc[dt][4 * g4 + 2], acc[dt][4 * g4 + 3]);
-      *(uint2*)(orow + dt * 32 + 8 * g4 + 4 * h5) = w;
+      w.x = pack2bf(dk[dt][4 * g4 + 0], dk[dt][4 * g4 + 1]);
+      w.y = pack2bf(dk[dt][4 * g4 + 2], dk[dt][4 * g4 + 3]);
+      *(uint2*)(krow_o + dt * 32 + 8 * g4 + 4 * h5) = w;
+      w.x = pack2bf(dv[dt][4 * g4 + 0], dv[dt][4 * g4 + 1]);
+      w.y = pack2bf(dv[dt][4 * g4 + 2], dv[dt][4 * g4 + 3]);
+      *(uint2*)(krow_o + d + dt * 32 + 8 * g4 + 4 * h5) = w;
     }
 }
 
@@ -441,8 +491,7 @@ extern "C" int pero_attention_bwd(const void* qkv, const void* out, const void* 
   static bool attr = false;
   if (!attr) {
     hipFuncSetAttribute((const void*)attn_bwd_dq_k, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * AT_TILE_BYTES);
-    hipFuncSetAttribute((const void*)attn_bwd_dkv_k<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * AT_TILE_BYTES + 1024);
-    hipFuncSetAttribute((const void*)attn_bwd_dkv_k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * AT_TILE_BYTES + 1024);
+    hipFuncSetAttribute((const void*)attn_bwd_dkv2_k, hipFuncAttributeMaxDynamicSharedMemorySize, AT_DKV2_LDS);
     attr = true;
   }
   const float scale = (float)(1.0 / sqrt((double)head_dim));
@@ -451,9 +500,7 @@ extern "C" int pero_attention_bwd(const void* qkv, const void* out, const void* 
   dim3 grid((unsigned)(N * num_heads * (S / 128))), block(256);
   hipLaunchKernelGGL(attn_bwd_dq_k, grid, block, 2 * AT_TILE_BYTES, st, (const bf16raw*)qkv, (const bf16raw*)out, (const bf16raw*)dout, lse,
                      dvec, (bf16raw*)dqkv, (int)S, (int)num_heads, c, scale);
-  hipLaunchKernelGGL(attn_bwd_dkv_k<0>, grid, block, 2 * AT_TILE_BYTES + 1024, st, (const bf16raw*)qkv, (const bf16raw*)dout, lse, dvec,
-                     (bf16raw*)dqkv, (int)S, (int)num_heads, c, scale);
-  hipLaunchKernelGGL(attn_bwd_dkv_k<1>, grid, block, 2 * AT_TILE_BYTES + 1024, st, (const bf16raw*)qkv, (const bf16raw*)dout, lse, dvec,
+  hipLaunchKernelGGL(attn_bwd_dkv2_k, grid, block, AT_DKV2_LDS, st, (const bf16raw*)qkv, (const bf16raw*)dout, lse, dvec,
                      (bf16raw*)dqkv, (int)S, (int)num_heads, c, scale);
   PERO_CHECK_LAUNCH("pero_attention_bwd");
   return PERO_OK;
