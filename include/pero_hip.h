@@ -110,9 +110,10 @@ int pero_softmax_bwd(const void* p, const float* dp, void* ds, int64_t rows, int
  * batched pero_gemm + pero_softmax_* path. */
 int pero_attention_fwd(const void* qkv, void* out, float* lse, int64_t N, int64_t S, int64_t num_heads,
                        int64_t head_dim, int dtype, void* stream);
-/* dqkv (N*S, 3d) from dout (N*S, d); dvec (N*nh, S) f32 scratch (row sums of dout*out) */
+/* dqkv (N*S, 3d) from dout (N*S, d); dvec (N*nh, S) f32 scratch (row sums of dout*out).  dbias (f32 [3d], may be null):
+ * the column sums of dqkv - in_proj's bias gradient - are ACCUMULATED into it from the kernels' staged output tiles. */
 int pero_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* dvec, void* dqkv,
-                       int64_t N, int64_t S, int64_t num_heads, int64_t head_dim, int dtype, void* stream);
+                       float* dbias, int64_t N, int64_t S, int64_t num_heads, int64_t head_dim, int dtype, void* stream);
 
 /* ---- masked cross entropy (masked_pretraining/model.py:72-95) -------------------------------------------
  * logits (rows, V); labels, mask int64 (rows).  loss_out[0] = mean CE over mask==1 rows

@@ -299,8 +299,52 @@ __device__ __forceinline__ bf8v img_tr_frag(const unsigned char* img, int rb, in
   return __builtin_bit_cast(bf8v, v);
 }
 
+// Epilogue of the backward kernels: a 128 x 128 gradient tile held as acc[dt][e] (row = this lane's query / key
+// `wave * 32 + r`, columns d = dt*32 + 8*(e>>2) + 4*h5 + (e&3)) goes through LDS as bf16 rows and leaves in 16-byte row
+// segments (the direct form was 16 scattered 8-byte stores per lane); the staged rows also give the tile's column sums -
+// this (line, head) block's share of in_proj's bias gradient - for 128 (x2) atomics instead of a pass over dqkv.
+// Image: 128 rows x 256 B, 8-byte granule index XORed with (row & 31): conflict-free ds_write_b64 and ds_read_b128.
+__device__ __forceinline__ void attn_store_tile(const f16v (&acc)[4], unsigned char* stg, bf16raw* out_base, long long ld,
+                                                float* colsum, int tid, int wave, int r, int h5) {
+  __syncthreads();  // the staging region is free (every wave is past its last tile read)
+  const int row_w = wave * 32 + r;
+#pragma unroll
+  for (int dt = 0; dt < 4; dt++)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; g4++) {
+      uint2 w;
+      w.x = pack2bf(acc[dt][4 * g4 + 0], acc[dt][4 * g4 + 1]);
+      w.y = pack2bf(acc[dt][4 * g4 + 2], acc[dt][4 * g4 + 3]);
+      const int g = dt * 8 + 2 * g4 + h5;
+      *(uint2*)(stg + row_w * 256 + ((g ^ (row_w & 31)) << 3)) = w;
+    }
+  __syncthreads();
+  const int ch = tid & 15;
+#pragma unroll 2
+  for (int i = 0; i < 8; i++) {
+    const int row = (tid >> 4) + 16 * i;
+    const int x = row & 31;
+    uint4 v = *(const uint4*)(stg + row * 256 + ((ch ^ (x >> 1)) << 4));
+    if (x & 1) { const unsigned t0 = v.x, t1 = v.y; v.x = v.z; v.y = v.w; v.z = t0; v.w = t1; }
+    *(uint4*)(out_base + (long long)row * ld + ch * 8) = v;
+  }
+  if (colsum) {  // thread: columns 2*c2, 2*c2 + 1 over rows quarter*32 .. +31
+    const int c2 = tid & 63, quarter = tid >> 6;
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll 4
+    for (int rr = 0; rr < 32; rr++) {
+      const int row = quarter * 32 + rr;
+      const unsigned w = *(const unsigned*)(stg + row * 256 + (((c2 >> 1) ^ (row & 31)) << 3) + (c2 & 1) * 4);
+      s0 += __uint_as_float(w << 16);
+      s1 += __uint_as_float(w & 0xffff0000u);
+    }
+    atomicAdd(colsum + 2 * c2, s0);
+    atomicAdd(colsum + 2 * c2 + 1, s1);
+  }
+}
+
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_k(const bf16raw* qkv, const bf16raw* out, const bf16raw* dout, const float* lse2,
-                                                        float* dvec, bf16raw* dqkv, int S, int nh, float c, float scale) {
+                                                        float* dvec, bf16raw* dqkv, float* dbias, int S, int nh, float c, float scale) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h5 = lane >> 5, r = lane & 31;
   const int nqb = S >> 7;
@@ -375,16 +419,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_k(const bf16raw* qkv, cons
       }
     }
   }
-  bf16raw* orow = dqkv + ((long long)line * S + q) * ld + head * 128;
-#pragma unroll
-  for (int dt = 0; dt < 4; dt++)
-#pragma unroll
-    for (int g4 = 0; g4 < 4; g4++) {
-      uint2 w;
-      w.x = pack2bf(dq[dt][4 * g4 + 0], dq[dt][4 * g4 + 1]);
-      w.y = pack2bf(dq[dt][4 * g4 + 2], dq[dt][4 * g4 + 3]);
-      *(uint2*)(orow + dt * 32 + 8 * g4 + 4 * h5) = w;
-    }
+  attn_store_tile(dq, smem, dqkv + ((long long)line * S + qb * 128) * ld + head * 128, ld, dbias ? dbias + head * 128 : nullptr, tid,
+                  wave, r, h5);
 }
 
 // dK and dV in ONE pass (4 products: S, dP, dV^T += dO^T P, dK^T += Q^T dS; key on the lane).  The two-launch form read
@@ -394,7 +430,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_k(const bf16raw* qkv, cons
 // lives in LDS (read as the B operand of dP) and Q / dO arrive in 32-query stages (8 + 8 KiB, double-buffered), so the
 // footprint stays at 64.5 KiB = two workgroups per CU.
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv2_k(const bf16raw* qkv, const bf16raw* dout, const float* lse2, const float* dvec,
-                                                          bf16raw* dqkv, int S, int nh, float c, float scale) {
+                                                          bf16raw* dqkv, float* dbias, int S, int nh, float c, float scale) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* vimg = smem + 4 * AT_SUB_BYTES;
   float* lds_ld = (float*)(smem + 4 * AT_SUB_BYTES + AT_TILE_BYTES);  // [2 buffers][32 lse2 | 32 D]
@@ -467,23 +503,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv2_k(const bf16raw* qkv, co
     }
     if (sq + 1 < nsub && tid < 64) lds_ld[((sq + 1) & 1) * 64 + tid] = nstat;  // visible after the next barrier
   }
-  bf16raw* krow_o = dqkv + ((long long)line * S + key) * ld + d + head * 128;
-#pragma unroll
-  for (int dt = 0; dt < 4; dt++)
-#pragma unroll
-    for (int g4 = 0; g4 < 4; g4++) {
-      uint2 w;
-      w.x = pack2bf(dk[dt][4 * g4 + 0], dk[dt][4 * g4 + 1]);
-      w.y = pack2bf(dk[dt][4 * g4 + 2], dk[dt][4 * g4 + 3]);
-      *(uint2*)(krow_o + dt * 32 + 8 * g4 + 4 * h5) = w;
-      w.x = pack2bf(dv[dt][4 * g4 + 0], dv[dt][4 * g4 + 1]);
-      w.y = pack2bf(dv[dt][4 * g4 + 2], dv[dt][4 * g4 + 3]);
-      *(uint2*)(krow_o + d + dt * 32 + 8 * g4 + 4 * h5) = w;
-    }
+  bf16raw* tile_o = dqkv + ((long long)line * S + kb * 128) * ld + d + head * 128;  // dK tile; dV tile = + d columns
+  attn_store_tile(dk, smem, tile_o, ld, dbias ? dbias + d + head * 128 : nullptr, tid, wave, r, h5);
+  attn_store_tile(dv, smem, tile_o + d, ld, dbias ? dbias + 2 * d + head * 128 : nullptr, tid, wave, r, h5);
 }
 
 extern "C" int pero_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* dvec, void* dqkv,
-                                  int64_t N, int64_t S, int64_t num_heads, int64_t head_dim, int dtype, void* stream) {
+                                  float* dbias, int64_t N, int64_t S, int64_t num_heads, int64_t head_dim, int dtype, void* stream) {
   PERO_REQUIRE(qkv && out && dout && lse && dvec && dqkv, "pero_attention_bwd: null pointer");
   PERO_REQUIRE(dtype == PERO_BF16 && head_dim == 128 && S % 128 == 0 && S > 0 && N > 0 && num_heads > 0,
                "pero_attention_bwd: fused kernel needs bf16, head_dim 128, S %% 128 == 0");
@@ -499,9 +525,9 @@ extern "C" int pero_attention_bwd(const void* qkv, const void* out, const void* 
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((unsigned)(N * num_heads * (S / 128))), block(256);
   hipLaunchKernelGGL(attn_bwd_dq_k, grid, block, 2 * AT_TILE_BYTES, st, (const bf16raw*)qkv, (const bf16raw*)out, (const bf16raw*)dout, lse,
-                     dvec, (bf16raw*)dqkv, (int)S, (int)num_heads, c, scale);
+                     dvec, (bf16raw*)dqkv, dbias, (int)S, (int)num_heads, c, scale);
   hipLaunchKernelGGL(attn_bwd_dkv2_k, grid, block, AT_DKV2_LDS, st, (const bf16raw*)qkv, (const bf16raw*)dout, lse, dvec,
-                     (bf16raw*)dqkv, (int)S, (int)num_heads, c, scale);
+                     (bf16raw*)dqkv, dbias, (int)S, (int)num_heads, c, scale);
   PERO_CHECK_LAUNCH("pero_attention_bwd");
   return PERO_OK;
 }

@@ -194,11 +194,14 @@ def layer_bwd(dt2, L, saved, n, s, h, dtype, side=None):
     dy1 = ops.layernorm_bwd(dt1, y1, mean1, rstd1, L.norm1.weight.detach(), ensure_grad(L.norm1.weight),
                             ensure_grad(L.norm1.bias), ensure_grad(at.out_proj.bias))
     da = linear_bwd(dy1, a, at.out_proj.weight, at.out_proj.bias, dtype, bias_grad_done=True, side=side)
+    fuse_bq = False
     if p.dim() == 2:
-        dqkv = ops.attention_bwd_fused(qkv, a, da, p, n, s, h)
+        # in_proj's bias gradient = column sums of dqkv: out of the attention kernels' staged output tiles
+        fuse_bq = FUSE_BIAS_GRAD and at.in_proj_bias is not None and at.in_proj_bias.requires_grad
+        dqkv = ops.attention_bwd_fused(qkv, a, da, p, n, s, h, dbias=ensure_grad(at.in_proj_bias) if fuse_bq else None)
     else:
         dqkv = attention_bwd(qkv, p, da, n, s, h)
-    return linear_bwd(dqkv, t, at.in_proj_weight, at.in_proj_bias, dtype, residual=dy1, side=side)
+    return linear_bwd(dqkv, t, at.in_proj_weight, at.in_proj_bias, dtype, residual=dy1, side=side, bias_grad_done=fuse_bq)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -125,11 +125,13 @@ def attention_fwd_fused(qkv, n, s, h):
     return out, lse
 
 
-def attention_bwd_fused(qkv, out, dout, lse, n, s, h):
+def attention_bwd_fused(qkv, out, dout, lse, n, s, h, dbias=None):
+    """dbias (f32 [3d], optional): in_proj's bias gradient (column sums of dqkv) is accumulated into it by the kernels."""
     d = qkv.shape[1] // 3
     dqkv = torch.empty_like(qkv)
     dvec = torch.empty((n * h, s), device=qkv.device, dtype=torch.float32)
-    call("pero_attention_bwd", ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(dvec), ptr(dqkv), n, s, h, d // h, dt(qkv), stream())
+    call("pero_attention_bwd", ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(dvec), ptr(dqkv), ptr(dbias), n, s, h, d // h, dt(qkv),
+         stream())
     return dqkv
 
 

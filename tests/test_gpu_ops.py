@@ -248,6 +248,12 @@ def test_fused_attention_fwd_bwd(ops, n, s, h):
         assert err < 3e-2, (name, err)
         a, b = dqkv[:, sl].double().cpu().flatten(), gref[:, sl].flatten()
         assert float(a @ b / (a.norm() * b.norm())) > 0.9995, name
+    # fused in_proj bias gradient: the column sums of the stored dqkv, accumulated into the given vector
+    dbias = torch.full((3 * d,), 2.0, device="cuda")
+    dqkv2 = ops.attention_bwd_fused(dev(qkv), out, dev(dout), lse, n, s, h, dbias=dbias)
+    assert torch.equal(dqkv2, dqkv)
+    want = 2.0 + dqkv.float().sum(0)
+    assert float((dbias - want).abs().max()) <= 1e-3 * max(1.0, float(want.abs().max()))
 
 
 # ------------------------------------------------------------------------------------------ row kernels
