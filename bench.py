@@ -124,6 +124,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dp-no-overlap", action="store_true", help="data parallel: reduce all gradients after the backward pass (A/B of the bucket hooks)")
+    ap.add_argument("--dp-layers-per-bucket", type=int, default=2)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -147,7 +149,7 @@ def main():
     bf16 = args.dtype == "bf16"
     model, opt, sched, trainer = build(device, bf16)
     if dist.is_initialized():
-        trainer.data_parallel = DataParallel(model, opt)
+        trainer.data_parallel = DataParallel(model, opt, overlap=not args.dp_no_overlap, layers_per_bucket=args.dp_layers_per_bucket)
     batches = synthetic(rank, args.batch, device)
 
     def step(i):
