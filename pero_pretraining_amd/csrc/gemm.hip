@@ -502,7 +502,7 @@ static int gemm_dispatch(const void* A, const void* B, void* C, const float* bia
       PERO_CHECK_LAUNCH("pero_gemm(w256)");
       return PERO_OK;
     }
-    if ((g_gemm_policy == 10 || g_gemm_policy == 12 || (g_gemm_policy == 11 && K >= 1024) || (g_gemm_policy == 0 && (flags & PERO_GEMM_TILE_V))) && !forced0 && !atomic && pero_launch_gemm_v256(want_cs ? pc : p, batch, k_split, ta, tb, out_dtype == PERO_F32, st)) {
+    if ((g_gemm_policy == 10 || g_gemm_policy == 12 || (g_gemm_policy == 11 && K >= 1024) || (g_gemm_policy == 0 && (flags & PERO_GEMM_TILE_V) && t256 >= 192)) && !forced0 && !atomic && pero_launch_gemm_v256(want_cs ? pc : p, batch, k_split, ta, tb, out_dtype == PERO_F32, st)) {
       *colsum_fused = want_cs;
       PERO_CHECK_LAUNCH("pero_gemm(v256)");
       return PERO_OK;
