@@ -111,9 +111,11 @@ int pero_softmax_bwd(const void* p, const float* dp, void* ds, int64_t rows, int
 int pero_attention_fwd(const void* qkv, void* out, float* lse, int64_t N, int64_t S, int64_t num_heads,
                        int64_t head_dim, int dtype, void* stream);
 /* dqkv (N*S, 3d) from dout (N*S, d); dvec (N*nh, S) f32 scratch (row sums of dout*out).  dbias (f32 [3d], may be null):
- * the column sums of dqkv - in_proj's bias gradient - are ACCUMULATED into it from the kernels' staged output tiles. */
+ * the column sums of dqkv - in_proj's bias gradient - are ACCUMULATED into it: per-workgroup partial rows from the kernels'
+ * staged output tiles into work (f32, 3 * N * nh * (S/128) * 128 elements; required with dbias), then one small reduction. */
 int pero_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* dvec, void* dqkv,
-                       float* dbias, int64_t N, int64_t S, int64_t num_heads, int64_t head_dim, int dtype, void* stream);
+                       float* dbias, float* work, int64_t N, int64_t S, int64_t num_heads, int64_t head_dim, int dtype,
+                       void* stream);
 
 /* ---- masked cross entropy (masked_pretraining/model.py:72-95) -------------------------------------------
  * logits (rows, V); labels, mask int64 (rows).  loss_out[0] = mean CE over mask==1 rows

@@ -30,7 +30,7 @@ SIGNATURES = {
     "pero_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _f32, _i32, _vp],
     "pero_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp],
     "pero_attention_fwd": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp],
-    "pero_attention_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp],
+    "pero_attention_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp],
     "pero_softmax_fwd": [_vp, _vp, _i64, _i64, _f32, _i32, _vp],
     "pero_softmax_bwd": [_vp, _vp, _vp, _i64, _i64, _f32, _i32, _vp],
     "pero_masked_ce_fwd": [_vp, _vp, _vp, _f32, _vp, _vp, _i64, _i64, _i32, _vp],

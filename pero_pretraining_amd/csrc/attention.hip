@@ -328,7 +328,7 @@ __device__ __forceinline__ void attn_store_tile(const f16v (&acc)[4], unsigned c
     if (x & 1) { const unsigned t0 = v.x, t1 = v.y; v.x = v.z; v.y = v.w; v.z = t0; v.w = t1; }
     *(uint4*)(out_base + (long long)row * ld + ch * 8) = v;
   }
-  if (colsum) {  // thread: columns 2*c2, 2*c2 + 1 over rows quarter*32 .. +31
+  if (colsum) {  // thread: columns 2*c2, 2*c2 + 1 over rows quarter*32 .. +31; the four quarters meet in LDS
     const int c2 = tid & 63, quarter = tid >> 6;
     float s0 = 0.f, s1 = 0.f;
 #pragma unroll 4
@@ -338,9 +338,34 @@ __device__ __forceinline__ void attn_store_tile(const f16v (&acc)[4], unsigned c
       s0 += __uint_as_float(w << 16);
       s1 += __uint_as_float(w & 0xffff0000u);
     }
-    atomicAdd(colsum + 2 * c2, s0);
-    atomicAdd(colsum + 2 * c2 + 1, s1);
+    __syncthreads();  // every thread is done reading the staged tile
+    float* red = (float*)stg;
+    red[quarter * 128 + 2 * c2] = s0;
+    red[quarter * 128 + 2 * c2 + 1] = s1;
+    __syncthreads();
+    // one partial row per workgroup and gradient, summed by attn_bias_reduce_k: atomics into the 128 addresses of a head
+    // from its 512 workgroups ran ~50 us longer per kernel than this
+    if (tid < 128) colsum[tid] = (red[tid] + red[128 + tid]) + (red[256 + tid] + red[384 + tid]);
   }
+}
+
+// dbias[which * d + head * 128 + c] += sum over the workgroups (line, block) of partial[which][(lh, blk)][c], lh = line * nh + head.
+// Grid (heads, 3, 16 slices of the workgroup list): 16 atomics per address.
+__global__ __launch_bounds__(128) void attn_bias_reduce_k(const float* partial, float* dbias, int nlines, int nh, int nblk) {
+  const int c = threadIdx.x, head = blockIdx.x, which = blockIdx.y;
+  const long long nwg = (long long)nlines * nh * nblk;
+  const float* p = partial + (long long)which * nwg * 128;
+  const int per_head = nlines * nblk;  // workgroups of this head
+  const int chunk = (per_head + gridDim.z - 1) / gridDim.z;
+  const int i0 = blockIdx.z * chunk, i1 = i0 + chunk < per_head ? i0 + chunk : per_head;
+  float s0 = 0.f, s1 = 0.f;
+  int i = i0;
+  for (; i + 2 <= i1; i += 2) {
+    s0 += p[(((long long)(i / nblk) * nh + head) * nblk + i % nblk) * 128 + c];
+    s1 += p[(((long long)((i + 1) / nblk) * nh + head) * nblk + (i + 1) % nblk) * 128 + c];
+  }
+  if (i < i1) s0 += p[(((long long)(i / nblk) * nh + head) * nblk + i % nblk) * 128 + c];
+  if (i0 < i1) atomicAdd(dbias + (long long)which * nh * 128 + head * 128 + c, s0 + s1);
 }
 
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_k(const bf16raw* qkv, const bf16raw* out, const bf16raw* dout, const float* lse2,
@@ -419,8 +444,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_k(const bf16raw* qkv, cons
       }
     }
   }
-  attn_store_tile(dq, smem, dqkv + ((long long)line * S + qb * 128) * ld + head * 128, ld, dbias ? dbias + head * 128 : nullptr, tid,
-                  wave, r, h5);
+  // dbias: partial-sum workspace [3][workgroups][128] (q, k, v); this kernel fills plane 0
+  attn_store_tile(dq, smem, dqkv + ((long long)line * S + qb * 128) * ld + head * 128, ld,
+                  dbias ? dbias + ((long long)lh * nqb + qb) * 128 : nullptr, tid, wave, r, h5);
 }
 
 // dK and dV in ONE pass (4 products: S, dP, dV^T += dO^T P, dK^T += Q^T dS; key on the lane).  The two-launch form read
@@ -504,16 +530,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv2_k(const bf16raw* qkv, co
     if (sq + 1 < nsub && tid < 64) lds_ld[((sq + 1) & 1) * 64 + tid] = nstat;  // visible after the next barrier
   }
   bf16raw* tile_o = dqkv + ((long long)line * S + kb * 128) * ld + d + head * 128;  // dK tile; dV tile = + d columns
-  attn_store_tile(dk, smem, tile_o, ld, dbias ? dbias + d + head * 128 : nullptr, tid, wave, r, h5);
-  attn_store_tile(dv, smem, tile_o + d, ld, dbias ? dbias + 2 * d + head * 128 : nullptr, tid, wave, r, h5);
+  const long long nwg = gridDim.x;  // planes 1 (dK) and 2 (dV) of the partial-sum workspace
+  attn_store_tile(dk, smem, tile_o, ld, dbias ? dbias + (nwg + (long long)lh * nkb + kb) * 128 : nullptr, tid, wave, r, h5);
+  attn_store_tile(dv, smem, tile_o + d, ld, dbias ? dbias + (2 * nwg + (long long)lh * nkb + kb) * 128 : nullptr, tid, wave, r, h5);
 }
 
 extern "C" int pero_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* dvec, void* dqkv,
-                                  float* dbias, int64_t N, int64_t S, int64_t num_heads, int64_t head_dim, int dtype, void* stream) {
+                                  float* dbias, float* work, int64_t N, int64_t S, int64_t num_heads, int64_t head_dim, int dtype,
+                                  void* stream) {
   PERO_REQUIRE(qkv && out && dout && lse && dvec && dqkv, "pero_attention_bwd: null pointer");
   PERO_REQUIRE(dtype == PERO_BF16 && head_dim == 128 && S % 128 == 0 && S > 0 && N > 0 && num_heads > 0,
                "pero_attention_bwd: fused kernel needs bf16, head_dim 128, S %% 128 == 0");
   PERO_REQUIRE(aligned16(qkv) && aligned16(out) && aligned16(dout) && aligned16(dqkv), "pero_attention_bwd: 16-byte alignment");
+  PERO_REQUIRE(!dbias || work, "pero_attention_bwd: dbias needs the partial-sum workspace");
   static bool attr = false;
   if (!attr) {
     hipFuncSetAttribute((const void*)attn_bwd_dq_k, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * AT_TILE_BYTES);
@@ -525,9 +554,11 @@ extern "C" int pero_attention_bwd(const void* qkv, const void* out, const void* 
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((unsigned)(N * num_heads * (S / 128))), block(256);
   hipLaunchKernelGGL(attn_bwd_dq_k, grid, block, 2 * AT_TILE_BYTES, st, (const bf16raw*)qkv, (const bf16raw*)out, (const bf16raw*)dout, lse,
-                     dvec, (bf16raw*)dqkv, dbias, (int)S, (int)num_heads, c, scale);
+                     dvec, (bf16raw*)dqkv, dbias ? work : nullptr, (int)S, (int)num_heads, c, scale);
   hipLaunchKernelGGL(attn_bwd_dkv2_k, grid, block, AT_DKV2_LDS, st, (const bf16raw*)qkv, (const bf16raw*)dout, lse, dvec,
-                     (bf16raw*)dqkv, dbias, (int)S, (int)num_heads, c, scale);
+                     (bf16raw*)dqkv, dbias ? work : nullptr, (int)S, (int)num_heads, c, scale);
+  if (dbias)
+    hipLaunchKernelGGL(attn_bias_reduce_k, dim3((unsigned)num_heads, 3, 16), dim3(128), 0, st, work, dbias, (int)N, (int)num_heads, (int)(S / 128));
   PERO_CHECK_LAUNCH("pero_attention_bwd");
   return PERO_OK;
 }

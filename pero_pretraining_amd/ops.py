@@ -130,8 +130,9 @@ def attention_bwd_fused(qkv, out, dout, lse, n, s, h, dbias=None):
     d = qkv.shape[1] // 3
     dqkv = torch.empty_like(qkv)
     dvec = torch.empty((n * h, s), device=qkv.device, dtype=torch.float32)
-    call("pero_attention_bwd", ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(dvec), ptr(dqkv), ptr(dbias), n, s, h, d // h, dt(qkv),
-         stream())
+    work = torch.empty(3 * n * h * (s // 128) * 128, device=qkv.device, dtype=torch.float32) if dbias is not None else None
+    call("pero_attention_bwd", ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(dvec), ptr(dqkv), ptr(dbias), ptr(work), n, s, h, d // h,
+         dt(qkv), stream())
     return dqkv
 
 

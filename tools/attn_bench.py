@@ -19,5 +19,7 @@ for n, s in [(256, 256), (128, 512), (64, 1024), (32, 2048)]:
     out, lse = ops.attention_fwd_fused(qkv, n, s, h)
     tf = bench(lambda: ops.attention_fwd_fused(qkv, n, s, h))
     tb = bench(lambda: ops.attention_bwd_fused(qkv, out, dout, lse, n, s, h))
+    db = torch.zeros(3 * h * hd, device="cuda")
+    tbb = bench(lambda: ops.attention_bwd_fused(qkv, out, dout, lse, n, s, h, dbias=db))
     fl = 4.0 * s * s * hd * n * h
-    print(f"N={n:4d} S={s:5d}: fwd {tf:7.1f} us {fl/tf/1e6:6.1f} TF | bwd {tb:7.1f} us {2.5*fl/tb/1e6:6.1f} TF useful ({3.5*fl/tb/1e6:6.1f} executed)")
+    print(f"N={n:4d} S={s:5d}: fwd {tf:7.1f} us {fl/tf/1e6:6.1f} TF | bwd {tb:7.1f} us {2.5*fl/tb/1e6:6.1f} TF useful ({3.0*fl/tb/1e6:6.1f} executed) | with in_proj bias gradient {tbb:7.1f} us")
