@@ -5,19 +5,35 @@ the parameter changed (`_version` / storage) since the copy was made.  The fused
 (`optim.FusedAdam`) writes the bf16 copy of the whole flat parameter buffer inside its own kernel and
 registers the fresh views through `put`, so a training step issues no separate cast.
 """
+import weakref
+
 import torch
 
 from . import ops
 
-_cache = {}
+_cache = {}  # id(p) -> (key, bf16 copy, is_optimizer_view, weakref to p): ids are reused once a parameter dies, so an entry only
+             # counts while its weak reference still points at the SAME object (a stale hit served another model's weights)
 
 
 def _key(p):
     return (p._version, p.data_ptr(), tuple(p.shape))
 
 
-def get(p):
+def _ref(p):
+    key = id(p)
+    return weakref.ref(p, lambda _r: _cache.pop(key, None))  # runs at the parameter's death, before its id can be reused
+
+
+def _entry(p):
     ent = _cache.get(id(p))
+    if ent is not None and ent[3]() is not p:
+        del _cache[id(p)]
+        return None
+    return ent
+
+
+def get(p):
+    ent = _entry(p)
     k = _key(p)
     if ent is not None and ent[0] == k:
         return ent[1]
@@ -35,13 +51,13 @@ def get(p):
         tmp = torch.empty(pad.numel(), device=p.device, dtype=torch.bfloat16)
         ops.cast_to_bf16(pad, tmp)
         dst.reshape(-1).copy_(tmp[:n])
-    _cache[id(p)] = (k, dst, ent[2] if ent is not None else False)
+    _cache[id(p)] = (k, dst, ent[2] if ent is not None else False, _ref(p))
     return dst
 
 
 def put(p, lp_view):
     """Register `lp_view` (bf16, already holding the current value of p) as p's copy."""
-    _cache[id(p)] = (_key(p), lp_view, True)
+    _cache[id(p)] = (_key(p), lp_view, True, _ref(p))
 
 
 def weight(p, dtype):

@@ -122,3 +122,21 @@ def test_positional_table_and_offsets(golden):
     expect = torch.randint(0, 4096 - 16, (4,))
     torch.manual_seed(3)
     assert torch.equal(pm.draw_offsets(4, 16, torch.device("cpu")), expect)
+
+
+def test_lowp_cache_entries_die_with_their_parameter():
+    """The bf16 weight cache is keyed by id(parameter); ids are reused after death, so an entry must not outlive its parameter
+    (a stale hit once served another model's weights to a freshly built one)."""
+    import gc
+    import torch
+    from pero_pretraining_amd import lowp
+    p = torch.nn.Parameter(torch.zeros(8))
+    lowp.put(p, torch.zeros(8, dtype=torch.bfloat16))
+    key = id(p)
+    assert key in lowp._cache
+    del p
+    gc.collect()
+    assert key not in lowp._cache
+    q = torch.nn.Parameter(torch.ones(8))
+    lowp._cache[id(q)] = (lowp._key(q), torch.zeros(8, dtype=torch.bfloat16), True, lowp.weakref.ref(torch.nn.Parameter(torch.zeros(1))))
+    assert lowp._entry(q) is None          # an entry whose weak reference is not this very object is discarded
