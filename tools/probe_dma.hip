@@ -37,11 +37,11 @@ __global__ __launch_bounds__(THREADS) void k(const unsigned char* X, long long l
   if (sink && tid == 0) sink[blockIdx.x] = *(unsigned*)smem;
 }
 template <int W, int STAGES, int THREADS>
-void run(const unsigned char* X, long long M, long long Kbytes, int share, unsigned* sink) {
+void run(const unsigned char* X, long long M, long long Kbytes, int share, unsigned* sink, size_t pad = 0) {
   const int rows = 256;
   const int wgs = (int)(M / rows) * share;
   const int ksteps = (int)(Kbytes / W);
-  const size_t lds = (size_t)STAGES * rows * W;
+  const size_t lds = (size_t)STAGES * rows * W + pad;
   hipFuncSetAttribute((const void*)k<W, STAGES, THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   hipLaunchKernelGGL((k<W, STAGES, THREADS>), dim3(wgs), dim3(THREADS), lds, 0, X, Kbytes, ksteps, share, rows, sink);
@@ -57,15 +57,18 @@ int main() {
   const long long M = 65536, Kbytes = 4096;  // 65536 x 2048 bf16 = 268 MB
   unsigned char* X; hipMalloc(&X, M * Kbytes + 4096); hipMemset(X, 1, M * Kbytes + 4096);
   unsigned* sink; hipMalloc(&sink, 4 * 4096);
-  for (int share : {1, 2, 4}) {
-    run<64, 3, 1024>(X, M, Kbytes, share, sink);
-    run<64, 5, 1024>(X, M, Kbytes, share, sink);
+  for (int share : {2, 4}) {
+    printf("-- W 128, 2 stages, two workgroups per CU (64 KiB each) vs one (padded to 96 KiB), by workgroup size\n");
     run<128, 2, 1024>(X, M, Kbytes, share, sink);
-    run<128, 3, 1024>(X, M, Kbytes, share, sink);
-    run<128, 4, 1024>(X, M, Kbytes, share, sink);
-    run<256, 2, 1024>(X, M, Kbytes, share, sink);
-    run<128, 3, 512>(X, M, Kbytes, share, sink);
-    run<128, 3, 256>(X, M, Kbytes, share, sink);
+    run<128, 2, 1024>(X, M, Kbytes, share, sink, 32768);
+    run<128, 2, 512>(X, M, Kbytes, share, sink);
+    run<128, 2, 512>(X, M, Kbytes, share, sink, 32768);
+    run<128, 2, 256>(X, M, Kbytes, share, sink);
+    run<128, 2, 256>(X, M, Kbytes, share, sink, 32768);
+    printf("-- W 64, 2 stages (32 KiB): up to 5 workgroups per CU; padded to 64 / 96 KiB: 2 / 1\n");
+    run<64, 2, 512>(X, M, Kbytes, share, sink);
+    run<64, 2, 512>(X, M, Kbytes, share, sink, 32768);
+    run<64, 2, 512>(X, M, Kbytes, share, sink, 65536);
   }
   return 0;
 }
