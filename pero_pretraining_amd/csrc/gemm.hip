@@ -498,6 +498,10 @@ static int gemm_dispatch(const void* A, const void* B, void* C, const float* bia
       PERO_CHECK_LAUNCH("pero_gemm(bf16 p128)");
       return PERO_OK;
     }
+    if (g_gemm_policy == 15 && !forced0 && !atomic && !want_cs && pero_launch_gemm_x256(p, batch, k_split, ta, tb, out_dtype == PERO_F32, st)) {
+      PERO_CHECK_LAUNCH("pero_gemm(x256)");
+      return PERO_OK;
+    }
     if (g_gemm_policy == 12 && !forced0 && !atomic && pero_launch_gemm_w256(p, batch, k_split, ta, tb, out_dtype == PERO_F32, st)) {
       PERO_CHECK_LAUNCH("pero_gemm(w256)");
       return PERO_OK;
@@ -511,7 +515,7 @@ static int gemm_dispatch(const void* A, const void* B, void* C, const float* bia
       PERO_CHECK_LAUNCH("pero_gemm(bf16 q256)");
       return PERO_OK;
     }
-    if ((g_gemm_policy == 7 || g_gemm_policy == 0 || g_gemm_policy == 11) && !forced0 && !atomic && pero_launch_gemm_r256(want_cs ? pc : p, batch, k_split, ta, tb, out_dtype == PERO_F32, st)) {
+    if ((g_gemm_policy == 7 || g_gemm_policy == 0 || g_gemm_policy == 11 || g_gemm_policy == 15) && !forced0 && !atomic && pero_launch_gemm_r256(want_cs ? pc : p, batch, k_split, ta, tb, out_dtype == PERO_F32, st)) {
       *colsum_fused = want_cs;
       PERO_CHECK_LAUNCH("pero_gemm(bf16 r256)");
       return PERO_OK;

@@ -38,6 +38,8 @@ bool pero_launch_gemm_r256(const GemmP& p, long long batch, int k_split, bool ta
 bool pero_launch_gemm_q256(const GemmP& p, long long batch, int k_split, bool ta, bool tb, bool out_f32, hipStream_t st);
 // host entry of the 256x256x64 sixteen-wave kernel (gemm_v.hip): whole 128-byte row segments per LDS-DMA lane group
 bool pero_launch_gemm_v256(const GemmP& p, long long batch, int k_split, bool ta, bool tb, bool out_f32, hipStream_t st);
+// host entry of the experimental four-wave 256x256x64 kernel (gemm_x.hip; NT products only)
+bool pero_launch_gemm_x256(const GemmP& p, long long batch, int k_split, bool ta, bool tb, bool out_f32, hipStream_t st);
 // host entry of the persistent 256x256x64 kernel (gemm_w.hip): epilogue overlapped with the next tile's main loop
 bool pero_launch_gemm_w256(const GemmP& p, long long batch, int k_split, bool ta, bool tb, bool out_f32, hipStream_t st);
 // host entry of the software-pipelined 128x128x32 kernel (gemm_p.hip)

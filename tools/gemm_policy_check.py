@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pero_pretraining_amd import ops, _lib
 pol = int(sys.argv[1])
 torch.manual_seed(0)
-M, N, K = 512, 768, 320 if pol != 10 else 384
+M, N, K = 512, 768, 320 if pol not in (10, 15) else 384
 bad = 0
 for ta in (False, True):
     for tb in (False, True):
