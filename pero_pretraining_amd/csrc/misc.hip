@@ -7,21 +7,31 @@
 // whole (c,h,p)-ordered patch rows (contiguous C*H*P elements per patch).
 // ---------------------------------------------------------------------------------------------
 #define PT_TOK 16
+// x / 255.0f for the 256 byte values, by the same IEEE division the reference performs (batch_operator.py:18), once per
+// block: the per-pixel division (a ~10-instruction sequence) and the integer divisions of the index arithmetic made the
+// first version of this kernel VALU-bound at 1.7 TB/s.
 template <typename T>
 __global__ __launch_bounds__(256) void patches_u8_k(const uint8_t* img, const int64_t* mask, const float* tile, T* out,
                                                     int H, int W, int C, int P, int S, int ldo) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  __shared__ float q255[256];
+  q255[threadIdx.x] = (float)threadIdx.x / 255.0f;
   const int n = blockIdx.y, s0 = blockIdx.x * PT_TOK;
   const int ntok = (S - s0) < PT_TOK ? (S - s0) : PT_TOK;
   const int rowbytes = ntok * P * C;
   const long long rowpitch = (long long)W * C;
   const uint8_t* src = img + ((long long)n * H) * rowpitch + (long long)s0 * P * C;
-  const int ldsp = PT_TOK * P * C;
+  // LDS row pitch: an ODD number of dwords - lanes walk the image rows (h) at a fixed column, and the unpadded 384-byte pitch
+  // (96 dwords) put all 40 rows on two banks (32-way conflict on every pixel read)
+  const int ldsp = (((PT_TOK * P * C + 3) >> 2) | 1) << 2;
   if ((rowbytes & 3) == 0 && (rowpitch & 3) == 0 && ((s0 * P * C) & 3) == 0 && ((uintptr_t)img & 3) == 0) {
     const int rw = rowbytes >> 2;
-    for (int i = threadIdx.x; i < H * rw; i += 256) {
-      const int h = i / rw, b = i - h * rw;
+    int h = threadIdx.x / rw, b = threadIdx.x - h * rw;  // element (h, b), advanced by 256 per iteration without divisions
+    const int dh = 256 / rw, db = 256 - dh * rw;
+    while (h < H) {
       *(unsigned*)(lds + h * ldsp + 4 * b) = *(const unsigned*)(src + h * rowpitch + 4 * b);
+      h += dh; b += db;
+      if (b >= rw) { b -= rw; h++; }
     }
   } else {
     for (int i = threadIdx.x; i < H * rowbytes; i += 256) {
@@ -30,21 +40,52 @@ __global__ __launch_bounds__(256) void patches_u8_k(const uint8_t* img, const in
     }
   }
   __syncthreads();
-  const int groups = ntok * C * H;  // one group = the P pixels of one (token, c, h)
-  const int pd = C * H * P;
-  for (int gidx = threadIdx.x; gidx < groups; gidx += 256) {
-    const int tok = gidx / (C * H), ch = gidx - tok * (C * H);
-    const int c = ch / H, h = ch - c * H;
-    const bool masked = mask && mask[(long long)n * S + s0 + tok] == 1;
-    T* o = out + ((long long)n * S + s0 + tok) * ldo + (long long)ch * P;
-    for (int e = 0; e < P; e++) {
-      const float v = masked ? tile[ch * P + e] : (float)lds[h * ldsp + (tok * P + e) * C + c] / 255.0f;
-      Elem<T>::st(o + e, v);
+  const int CH = C * H;  // one group = the P pixels of one (token, c, h); thread -> ch = tid % chp, tokens tid / chp, + step, ...
+  const int pd = CH * P;
+  int chp = 1;
+  while (chp < CH) chp <<= 1;               // 128 for C*H = 120
+  const int tstep = chp <= 256 ? 256 / chp : 1;
+  if (chp <= 256) {
+    const int ch = threadIdx.x & (chp - 1);
+    if (ch < CH) {
+      const int c = ch / H, h = ch - c * H;
+      const unsigned char* lrow = lds + h * ldsp + c;
+      for (int tok = threadIdx.x / chp; tok < ntok; tok += tstep) {
+        const bool masked = mask && mask[(long long)n * S + s0 + tok] == 1;
+        T* o = out + ((long long)n * S + s0 + tok) * ldo + (long long)ch * P;
+        if (sizeof(T) == 2 && P == 8 && (ldo & 7) == 0 && (((uintptr_t)out) & 15) == 0) {
+          float v[8];  // the 8 pixels of one (token, c, h) are 16 contiguous output bytes: one 16-byte store
+#pragma unroll
+          for (int e = 0; e < 8; e++) v[e] = masked ? tile[ch * 8 + e] : q255[lrow[(tok * 8 + e) * C]];
+          uint4 w;
+          w.x = pack2bf(v[0], v[1]); w.y = pack2bf(v[2], v[3]); w.z = pack2bf(v[4], v[5]); w.w = pack2bf(v[6], v[7]);
+          *(uint4*)o = w;
+        } else {
+          for (int e = 0; e < P; e++) Elem<T>::st(o + e, masked ? tile[ch * P + e] : q255[lrow[(tok * P + e) * C]]);
+        }
+      }
+    }
+  } else {  // very tall patches: generic index arithmetic
+    for (int gidx = threadIdx.x; gidx < ntok * CH; gidx += 256) {
+      const int tok = gidx / CH, ch = gidx - tok * CH;
+      const int c = ch / H, h = ch - c * H;
+      const bool masked = mask && mask[(long long)n * S + s0 + tok] == 1;
+      T* o = out + ((long long)n * S + s0 + tok) * ldo + (long long)ch * P;
+      for (int e = 0; e < P; e++) Elem<T>::st(o + e, masked ? tile[ch * P + e] : q255[lds[h * ldsp + (tok * P + e) * C + c]]);
     }
   }
-  for (int i = threadIdx.x; i < ntok * (ldo - pd); i += 256) {  // zero the row padding (GEMM-friendly pitch)
-    const int tok = i / (ldo - pd), e = i - tok * (ldo - pd);
-    Elem<T>::st(out + ((long long)n * S + s0 + tok) * ldo + pd + e, 0.f);
+  const int padn = ldo - pd;  // zero the row padding (GEMM-friendly pitch)
+  if (sizeof(T) == 2 && (padn & 7) == 0 && (pd & 7) == 0 && (ldo & 7) == 0 && (((uintptr_t)out) & 15) == 0) {
+    const int pc = padn >> 3;
+    for (int i = threadIdx.x; i < ntok * pc; i += 256) {
+      const int tok = i / pc, e = i - tok * pc;
+      *(uint4*)(out + ((long long)n * S + s0 + tok) * ldo + pd + 8 * e) = make_uint4(0, 0, 0, 0);
+    }
+  } else {
+    for (int i = threadIdx.x; i < ntok * padn; i += 256) {
+      const int tok = i / padn, e = i - tok * padn;
+      Elem<T>::st(out + ((long long)n * S + s0 + tok) * ldo + pd + e, 0.f);
+    }
   }
 }
 template <typename T>
@@ -95,7 +136,7 @@ extern "C" int pero_patches_from_u8(const uint8_t* images, const int64_t* mask, 
   PERO_REQUIRE(ld_out >= C * H * P, "pero_patches_from_u8: ld_out < C*H*P");
   PERO_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && P > 0 && W % P == 0 && N < 65536, "pero_patches_from_u8: bad sizes (W %% P must be 0)");
   const int S = (int)(W / P);
-  const size_t lds = (size_t)H * PT_TOK * P * C;
+  const size_t lds = (size_t)H * ((((PT_TOK * P * C + 3) >> 2) | 1) << 2);
   PERO_REQUIRE(lds <= 65536, "pero_patches_from_u8: H*16*P*C = %zu bytes exceeds the LDS staging budget", lds);
   dim3 grid((unsigned)((S + PT_TOK - 1) / PT_TOK), (unsigned)N), block(256);
   if (dtype == PERO_F32) hipLaunchKernelGGL((patches_u8_k<float>), grid, block, lds, (hipStream_t)stream, images, mask, tile, (float*)patches, (int)H, (int)W, (int)C, (int)P, S, (int)ld_out);
