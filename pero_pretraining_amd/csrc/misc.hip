@@ -7,15 +7,18 @@
 // whole (c,h,p)-ordered patch rows (contiguous C*H*P elements per patch).
 // ---------------------------------------------------------------------------------------------
 #define PT_TOK 16
-// x / 255.0f for the 256 byte values, by the same IEEE division the reference performs (batch_operator.py:18), once per
-// block: the per-pixel division (a ~10-instruction sequence) and the integer divisions of the index arithmetic made the
-// first version of this kernel VALU-bound at 1.7 TB/s.
+// x / 255.0f exactly as the reference's IEEE division (batch_operator.py:18), for byte values: reciprocal multiply plus one
+// fma correction step (q = x*r; q += fma(-q, 255, x) * r) - equal to the correctly rounded quotient for all 256 inputs
+// (tests/test_gpu_ops.py checks every value); a per-pixel division is a ~10-instruction sequence, a table in LDS conflicts.
+__device__ __forceinline__ float div255(unsigned char x) {
+  const float xf = (float)x, r = 1.0f / 255.0f;
+  const float q = xf * r;
+  return __builtin_fmaf(__builtin_fmaf(-q, 255.0f, xf), r, q);
+}
 template <typename T>
 __global__ __launch_bounds__(256) void patches_u8_k(const uint8_t* img, const int64_t* mask, const float* tile, T* out,
                                                     int H, int W, int C, int P, int S, int ldo) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  __shared__ float q255[256];
-  q255[threadIdx.x] = (float)threadIdx.x / 255.0f;
   const int n = blockIdx.y, s0 = blockIdx.x * PT_TOK;
   const int ntok = (S - s0) < PT_TOK ? (S - s0) : PT_TOK;
   const int rowbytes = ntok * P * C;
@@ -56,12 +59,12 @@ __global__ __launch_bounds__(256) void patches_u8_k(const uint8_t* img, const in
         if (sizeof(T) == 2 && P == 8 && (ldo & 7) == 0 && (((uintptr_t)out) & 15) == 0) {
           float v[8];  // the 8 pixels of one (token, c, h) are 16 contiguous output bytes: one 16-byte store
 #pragma unroll
-          for (int e = 0; e < 8; e++) v[e] = masked ? tile[ch * 8 + e] : q255[lrow[(tok * 8 + e) * C]];
+          for (int e = 0; e < 8; e++) v[e] = masked ? tile[ch * 8 + e] : div255(lrow[(tok * 8 + e) * C]);
           uint4 w;
           w.x = pack2bf(v[0], v[1]); w.y = pack2bf(v[2], v[3]); w.z = pack2bf(v[4], v[5]); w.w = pack2bf(v[6], v[7]);
           *(uint4*)o = w;
         } else {
-          for (int e = 0; e < P; e++) Elem<T>::st(o + e, masked ? tile[ch * P + e] : q255[lrow[(tok * P + e) * C]]);
+          for (int e = 0; e < P; e++) Elem<T>::st(o + e, masked ? tile[ch * P + e] : div255(lrow[(tok * P + e) * C]));
         }
       }
     }
@@ -71,7 +74,7 @@ __global__ __launch_bounds__(256) void patches_u8_k(const uint8_t* img, const in
       const int c = ch / H, h = ch - c * H;
       const bool masked = mask && mask[(long long)n * S + s0 + tok] == 1;
       T* o = out + ((long long)n * S + s0 + tok) * ldo + (long long)ch * P;
-      for (int e = 0; e < P; e++) Elem<T>::st(o + e, masked ? tile[ch * P + e] : q255[lds[h * ldsp + (tok * P + e) * C + c]]);
+      for (int e = 0; e < P; e++) Elem<T>::st(o + e, masked ? tile[ch * P + e] : div255(lds[h * ldsp + (tok * P + e) * C + c]));
     }
   }
   const int padn = ldo - pd;  // zero the row padding (GEMM-friendly pitch)

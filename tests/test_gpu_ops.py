@@ -477,3 +477,21 @@ def test_gemm_fused_column_sums(M, N, K, with_gate):
     want = 3.0 + ref.float().sum(0)
     err = (acc - want).abs().max().item()
     assert err <= 2e-2 * max(1.0, want.abs().max().item()), err   # f32 sums of pre-rounding values vs sums of bf16 values
+
+
+def test_patches_divide_every_byte_value_exactly():
+    """The front end's x / 255 (reciprocal multiply + one fma correction) equals the reference's IEEE division for all 256
+    byte values, in f32 and after the bf16 rounding."""
+    from pero_pretraining_amd import ops
+    vals = torch.arange(256, dtype=torch.uint8)
+    img = vals.repeat(40 * 8 * 3 * 2)[: 40 * 16 * 3].reshape(1, 40, 16, 3).contiguous()   # (N=1, H=40, W=16, C=3): 2 patches
+    img[0, :, :, 0] = vals[:16][None, :]; img[0, 0, :, 1] = vals[100:116]; img[0, 1, :, 2] = vals[240:256]
+    for rows in range(40):
+        img[0, rows, :, 1] = vals[(rows * 16) % 256:(rows * 16) % 256 + 16] if (rows * 16) % 256 + 16 <= 256 else vals[:16]
+    want = (img.float().permute(0, 3, 1, 2) / 255.0)                                      # reference arithmetic (f32 division)
+    ref_rows = want.reshape(1, 3, 40, 2, 8).permute(0, 3, 1, 2, 4).reshape(2, 960)         # (token, c*h*p)
+    got = ops.patches_from_u8(img.cuda(), None, None, 8, torch.float32)
+    assert torch.equal(got.cpu(), ref_rows)
+    got16 = ops.patches_from_u8(img.cuda(), None, None, 8, torch.bfloat16, pitch=1024)
+    assert torch.equal(got16[:, :960].cpu(), ref_rows.bfloat16()) and float(got16[:, 960:].abs().max()) == 0.0
+    assert set(img.reshape(-1).tolist()) == set(range(256))
