@@ -120,9 +120,11 @@ int pero_attention_bwd(const void* qkv, const void* out, const void* dout, const
 /* ---- masked cross entropy (masked_pretraining/model.py:72-95) -------------------------------------------
  * logits (rows, V); labels, mask int64 (rows).  loss_out[0] = mean CE over mask==1 rows
  * (+ unmasked_weight * mean CE over mask==0 & label>=0 rows when unmasked_weight >= 0; pass a negative
- * value for "None").  work: f32 workspace of 2*rows + 8 elements, kept by the caller for the backward
- * call (row losses, the two row counts, row logsumexps).  Empty selections give NaN like the reference.
+ * value for "None").  work: f32 workspace of PERO_CE_WORK(rows) elements, kept by the caller for the backward
+ * call (row losses, the two row counts, row logsumexps, partial sums of the final reduction).  Empty selections give NaN
+ * like the reference.
  * bwd: dlogits (dtype, rows x V) = dloss[0] * d loss / d logits (dloss: device f32 scalar, null = 1). */
+#define PERO_CE_WORK(rows) (2 * (rows) + 8 + 256)
 int pero_masked_ce_fwd(const void* logits, const int64_t* labels, const int64_t* mask, float unmasked_weight,
                        float* loss_out, float* work, int64_t rows, int64_t V, int dtype, void* stream);
 int pero_masked_ce_bwd(const void* logits, const int64_t* labels, const int64_t* mask, float unmasked_weight,

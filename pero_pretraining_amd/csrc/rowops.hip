@@ -297,6 +297,34 @@ __global__ __launch_bounds__(256) void ce_rows_k(const T* logits, const int64_t*
     return;
   }
   const T* lr = logits + row * V;
+  if (V == 4096 && (((uintptr_t)lr) & 15) == 0) {
+    // the whole row in registers (2 x 8 values per thread): one pass over memory, one barrier pair
+    float v[2][8];
+    load8<T>(lr + tid * 8, v[0]);
+    load8<T>(lr + 2048 + tid * 8, v[1]);
+    float mx = v[0][0];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int e = 0; e < 8; e++) mx = fmaxf(mx, v[i][e]);
+    mx = wave_max(mx);
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int e = 0; e < 8; e++) sum += expf(v[i][e] - mx);
+    sum = wave_sum(sum);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = sum;
+    __syncthreads();
+    sum = (red[0] + red[1]) + (red[2] + red[3]);
+    const float lse = logf(sum) + mx;
+    if (tid == 0) { work[row] = lse - Elem<T>::ld(lr + lab); work[rows + 8 + row] = lse; }
+    return;
+  }
   float mx = -INFINITY;
   for (int c = tid; c < V; c += 256) mx = fmaxf(mx, Elem<T>::ld(lr + c));
   mx = wave_max(mx);
@@ -317,34 +345,57 @@ __global__ __launch_bounds__(256) void ce_rows_k(const T* logits, const int64_t*
 template <typename T>
 __global__ __launch_bounds__(256) void ce_bwd_k(const T* logits, const int64_t* labels, const int64_t* mask, float uw,
                                                 const float* dloss, const float* work, T* dlogits, long long rows, int V) {
-  const long long row = blockIdx.x;
   const int tid = threadIdx.x;
+  const long long row = blockIdx.x;
+  {
   const long long lab = labels[row];
   const long long mk = mask[row];
   float w = 0.f;
   if (mk == 1) w = 1.0f / work[rows];
   else if (mk == 0 && lab >= 0 && uw >= 0.f) w = uw / work[rows + 1];
   const bool active = (mk == 1) || (mk == 0 && lab >= 0 && uw >= 0.f);
-  if (!active) {
-    for (int c = tid; c < V; c += 256) Elem<T>::st(dlogits + row * V + c, 0.f);
-    return;
-  }
+  const bool vec = (V & 7) == 0 && ((((uintptr_t)(dlogits + row * V)) | ((uintptr_t)(logits + row * V))) & 15) == 0;
+  if (!active) return;  // the buffer was zero-filled linearly before this launch: per-row zero stores from 65536 small
+                        // blocks (or a grid-stride loop) reached only 2.7 TB/s
+
   if (dloss) w *= dloss[0];
   const float lse = work[rows + 8 + row];
   const T* lr = logits + row * V;
+  if (vec) {
+    for (int c = tid * 8; c < V; c += 2048) {
+      float v[8];
+      load8<T>(lr + c, v);
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        float g = expf(v[e] - lse);
+        if (c + e == lab) g -= 1.0f;
+        v[e] = g * w;
+      }
+      store8<T>(dlogits + row * V + c, v);
+    }
+    return;
+  }
   for (int c = tid; c < V; c += 256) {
     float g = expf(Elem<T>::ld(lr + c) - lse);
     if (c == lab) g -= 1.0f;
     Elem<T>::st(dlogits + row * V + c, g * w);
   }
+  }
 }
-// counts + deterministic loss sums in one pass (1024 threads, fixed order): work[rows] = n_masked,
-// work[rows+1] = n_unmasked (read by the backward kernel), loss = sum_m/n_m (+ uw * sum_u/n_u)
-__global__ __launch_bounds__(1024) void ce_final_k(const int64_t* labels, const int64_t* mask, float uw, float* work,
-                                                   float* loss, long long rows) {
-  __shared__ float sm[4][16];
+// counts + deterministic loss sums: work[rows] = n_masked, work[rows+1] = n_unmasked (read by the backward kernel),
+// loss = sum_m/n_m (+ uw * sum_u/n_u).  Two levels, both in a fixed order (deterministic): CE_PARTS blocks sum a contiguous slice of the rows each into
+// work[rows + 8 + rows + 4 * part ..], the last block to finish (ticket in work[rows + 2]) adds the partials in index order.
+#define CE_PARTS 64
+__global__ __launch_bounds__(256) void ce_final_k(const int64_t* labels, const int64_t* mask, float uw, float* work,
+                                                  float* loss, long long rows) {
+  __shared__ float sm[4][4];
+  __shared__ int last;
+  float* partial = work + 2 * rows + 8;            // CE_PARTS x 4 floats (the launcher's workspace has room: see header)
+  unsigned* ticket = (unsigned*)(work + rows + 2);
+  const long long per = (rows + CE_PARTS - 1) / CE_PARTS;
+  const long long r0 = (long long)blockIdx.x * per, r1 = r0 + per < rows ? r0 + per : rows;
   float a = 0.f, b = 0.f, na = 0.f, nb = 0.f;
-  for (long long r = threadIdx.x; r < rows; r += 1024) {
+  for (long long r = r0 + threadIdx.x; r < r1; r += 256) {
     const long long mk = mask[r], lb = labels[r];
     const float w = work[r];
     if (mk == 1) { a += w; na += 1.f; }
@@ -355,14 +406,28 @@ __global__ __launch_bounds__(1024) void ce_final_k(const int64_t* labels, const 
   if ((threadIdx.x & 63) == 0) { sm[0][wv] = a; sm[1][wv] = b; sm[2][wv] = na; sm[3][wv] = nb; }
   __syncthreads();
   if (threadIdx.x == 0) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) partial[4 * blockIdx.x + q] = (sm[q][0] + sm[q][1]) + (sm[q][2] + sm[q][3]);
+    __threadfence();
+    last = atomicAdd(ticket, 1u) == CE_PARTS - 1;
+  }
+  __syncthreads();
+  __shared__ float pl[4 * CE_PARTS];
+  if (last) {
+    __threadfence();
+    pl[threadIdx.x] = ((volatile float*)partial)[threadIdx.x];  // 256 = 4 * CE_PARTS values, one per thread
+  }
+  __syncthreads();
+  if (last && threadIdx.x == 0) {
     float t[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int q = 0; q < 4; q++)
-      for (int i = 0; i < 16; i++) t[q] += sm[q][i];
+    for (int i = 0; i < CE_PARTS; i++)
+      for (int q = 0; q < 4; q++) t[q] += pl[4 * i + q];
     work[rows] = t[2];
     work[rows + 1] = t[3];
     float l = t[0] / t[2];
     if (uw >= 0.f) l += uw * (t[1] / t[3]);
     loss[0] = l;
+    *ticket = 0u;  // ready for the next launch on this workspace
   }
 }
 extern "C" int pero_masked_ce_fwd(const void* logits, const int64_t* labels, const int64_t* mask, float unmasked_weight,
@@ -373,7 +438,8 @@ extern "C" int pero_masked_ce_fwd(const void* logits, const int64_t* labels, con
   if (dtype == PERO_F32) hipLaunchKernelGGL((ce_rows_k<float>), dim3((unsigned)rows), dim3(256), 0, st, (const float*)logits, labels, mask, unmasked_weight, work, (long long)rows, (int)V);
   else if (dtype == PERO_BF16) hipLaunchKernelGGL((ce_rows_k<bf16raw>), dim3((unsigned)rows), dim3(256), 0, st, (const bf16raw*)logits, labels, mask, unmasked_weight, work, (long long)rows, (int)V);
   else PERO_REQUIRE(false, "pero_masked_ce_fwd: bad dtype");
-  hipLaunchKernelGGL(ce_final_k, dim3(1), dim3(1024), 0, st, labels, mask, unmasked_weight, work, loss_out, (long long)rows);
+  hipMemsetAsync(work + rows + 2, 0, sizeof(float), st);  // the reduction's ticket
+  hipLaunchKernelGGL(ce_final_k, dim3(CE_PARTS), dim3(256), 0, st, labels, mask, unmasked_weight, work, loss_out, (long long)rows);
   PERO_CHECK_LAUNCH("pero_masked_ce_fwd");
   return PERO_OK;
 }
@@ -383,6 +449,10 @@ extern "C" int pero_masked_ce_bwd(const void* logits, const int64_t* labels, con
   PERO_REQUIRE(logits && labels && mask && work && dlogits, "pero_masked_ce_bwd: null pointer");
   PERO_REQUIRE(rows > 0 && V > 0, "pero_masked_ce_bwd: bad sizes");
   hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(dlogits, 0, (size_t)rows * (size_t)V * (dtype == PERO_F32 ? 4 : 2), st) != hipSuccess) {
+    pero_set_error("pero_masked_ce_bwd: zero fill failed");
+    return PERO_E_LAUNCH;
+  }
   if (dtype == PERO_F32) hipLaunchKernelGGL((ce_bwd_k<float>), dim3((unsigned)rows), dim3(256), 0, st, (const float*)logits, labels, mask, unmasked_weight, dloss, work, (float*)dlogits, (long long)rows, (int)V);
   else if (dtype == PERO_BF16) hipLaunchKernelGGL((ce_bwd_k<bf16raw>), dim3((unsigned)rows), dim3(256), 0, st, (const bf16raw*)logits, labels, mask, unmasked_weight, dloss, work, (bf16raw*)dlogits, (long long)rows, (int)V);
   else PERO_REQUIRE(false, "pero_masked_ce_bwd: bad dtype");

@@ -141,7 +141,7 @@ def masked_ce_fwd(logits, labels, mask, unmasked_weight=None):
     _req_cuda(logits, labels, mask)
     rows, V = logits.shape
     loss = torch.empty(1, device=logits.device, dtype=torch.float32)
-    work = torch.empty(2 * rows + 8, device=logits.device, dtype=torch.float32)
+    work = torch.empty(2 * rows + 8 + 256, device=logits.device, dtype=torch.float32)  # PERO_CE_WORK(rows)
     call("pero_masked_ce_fwd", ptr(logits), ptr(labels), ptr(mask), -1.0 if unmasked_weight is None else float(unmasked_weight),
          ptr(loss), ptr(work), rows, V, dt(logits), stream())
     return loss, work
