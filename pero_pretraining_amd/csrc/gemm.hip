@@ -364,10 +364,12 @@ __global__ __launch_bounds__(256) void gemm_generic(GemmP p) {
 //   (16.9), 6 = shape mix of 2/3, 7 = r256, 8 = q256 16-wave 256x256x32 (16.7), 9 = p128 software-pipelined (18.3).
 static int g_gemm_policy = 0;
 static int g_splitk_items = 512;
+static int g_gemm_persistent = 1;  // PERO_GEMM_TILE_V products: persistent w256 (epilogue under the next tile's first stage) instead of v256
 int g_pero_splitk_xcd = 1;  // one k-slice per XCD for split-K products (gemm_o.hip)  // work items the automatic split-K aims for (k_split = 0)
 extern "C" int pero_set_option(const char* name, int value) {
   if (name && !strcmp(name, "gemm_policy")) { g_gemm_policy = value; return PERO_OK; }
   if (name && !strcmp(name, "splitk_xcd")) { g_pero_splitk_xcd = value; return PERO_OK; }
+  if (name && !strcmp(name, "gemm_persistent")) { g_gemm_persistent = value; return PERO_OK; }
   if (name && !strcmp(name, "splitk_items")) { g_splitk_items = value > 0 ? value : 256; return PERO_OK; }
   pero_set_error("pero_set_option: unknown option %s", name ? name : "(null)");
   return PERO_E_INVALID;
@@ -502,7 +504,7 @@ static int gemm_dispatch(const void* A, const void* B, void* C, const float* bia
       PERO_CHECK_LAUNCH("pero_gemm(x256)");
       return PERO_OK;
     }
-    if (g_gemm_policy == 12 && !forced0 && !atomic && pero_launch_gemm_w256(p, batch, k_split, ta, tb, out_dtype == PERO_F32, st)) {
+    if ((g_gemm_policy == 12 || (g_gemm_policy == 0 && g_gemm_persistent && (flags & PERO_GEMM_TILE_V) && t256 >= 192 && !want_cs)) && !forced0 && !atomic && pero_launch_gemm_w256(p, batch, k_split, ta, tb, out_dtype == PERO_F32, st)) {
       PERO_CHECK_LAUNCH("pero_gemm(w256)");
       return PERO_OK;
     }

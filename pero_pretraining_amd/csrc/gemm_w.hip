@@ -60,8 +60,6 @@ __device__ __forceinline__ void wstage_glds(const bf16raw* X, long long ld, long
                                    (__attribute__((address_space(3))) void*)(dst + 16384), 16, 0, 0);
 }
 
-#define W_EPI_STORES 8   // global stores per thread and epilogue with a bf16 output (4 chunks x 2 rows); f32 output: 16
-
 template <bool TA, bool TB, bool OUTF32>
 __global__ __launch_bounds__(1024, 4) void gemm_bf16_w256(GemmP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -73,7 +71,7 @@ __global__ __launch_bounds__(1024, 4) void gemm_bf16_w256(GemmP p) {
   const int q8 = nt >> 3, r8 = nt & 7;
   const bf16raw* A = (const bf16raw*)p.A;
   const bf16raw* B = (const bf16raw*)p.B;
-  const int nk = (int)(p.K / W_BK);
+  const int nk = (int)(p.K / W_BK);  // >= 2 (launcher)
   const int c8 = (tid & 31) * 8;
   const unsigned offA = wlane_off<TA>(p.lda, tid), offB = wlane_off<TB>(p.ldb, tid);
 
@@ -88,79 +86,96 @@ __global__ __launch_bounds__(1024, 4) void gemm_bf16_w256(GemmP p) {
   if (T >= nt) return;
   long long tm0, tn0;
   tile_of(T, tm0, tn0);
-  int slot = 0;
+
+  f4v acc[4][4];
+  // half step (see gemm_v.hip): 16 MFMAs on the fragments in registers; every register set is re-read from (nsa, nsb, nks)
+  // right after its last MFMA
+  auto half_step = [&](const unsigned char* nsa, const unsigned char* nsb, int nks, bf8v (&fa)[4], bf8v (&fb)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        if (i == 3) {
+          fb[j] = TB ? wfrag_kmajor(nsb, wn * 64 + j * 16, nks, lane) : wfrag_rowmajor(nsb, wn * 64 + j * 16, nks, lane);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, TB ? 2 : 1, 0);
+        }
+      }
+      fa[i] = TA ? wfrag_kmajor(nsa, wm * 64 + i * 16, nks, lane) : wfrag_rowmajor(nsa, wm * 64 + i * 16, nks, lane);
+      if (i < 3) __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, TA ? 2 : 1, 0);
+    }
+  };
+
+  // first tile: stage 0 -> slot 0, stage 1 -> slot 1, fragments of (0, ks 0)
+  int par = 0;  // slot of the current tile's stage 0
+  bf8v fa[4], fb[4];
   wstage_glds<TA>(A, p.lda, tm0, 0, offA, smem, tid);
   wstage_glds<TB>(B, p.ldb, tn0, 0, offB, smem + W_ABYTES, tid);
-  bool after_epilogue = false;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  lds_barrier();
+  wstage_glds<TA>(A, p.lda, tm0, W_BK, offA, smem + W_BUFBYTES, tid);
+  wstage_glds<TB>(B, p.ldb, tn0, W_BK, offB, smem + W_BUFBYTES + W_ABYTES, tid);
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    fa[i] = TA ? wfrag_kmajor(smem, wm * 64 + i * 16, 0, lane) : wfrag_rowmajor(smem, wm * 64 + i * 16, 0, lane);
+    fb[i] = TB ? wfrag_kmajor(smem + W_ABYTES, wn * 64 + i * 16, 0, lane) : wfrag_rowmajor(smem + W_ABYTES, wn * 64 + i * 16, 0, lane);
+  }
 
   for (;;) {
     long long nm0 = 0, nn0 = 0;
     const bool has_next = T + G < nt;
     if (has_next) tile_of(T + G, nm0, nn0);
-
-    f4v acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
       for (int j = 0; j < 4; j++) acc[i][j] = (f4v){0.f, 0.f, 0.f, 0.f};
 
     for (int t = 0; t < nk; t++) {
-      // stage (T, t) landed?  Right after an epilogue the W_EPI_STORES (or more) younger stores may stay in flight.
-      if (t == 0 && after_epilogue) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      lds_barrier();  // everyone's DMA of this stage landed; every wave is past its reads of the other slot
-      const unsigned char* sa = smem + slot * W_BUFBYTES;
-      const unsigned char* sb = sa + W_ABYTES;
-      unsigned char* da = smem + (slot ^ 1) * W_BUFBYTES;
-      if (t + 1 < nk) {
-        wstage_glds<TA>(A, p.lda, tm0, (long long)(t + 1) * W_BK, offA, da, tid);
-        wstage_glds<TB>(B, p.ldb, tn0, (long long)(t + 1) * W_BK, offB, da + W_ABYTES, tid);
-      } else if (has_next && nk > 1) {  // first stage of the next tile rides under this tile's last k-step and epilogue
-        wstage_glds<TA>(A, p.lda, nm0, 0, offA, da, tid);
-        wstage_glds<TB>(B, p.ldb, nn0, 0, offB, da + W_ABYTES, tid);
+      unsigned char* s0 = smem + ((par + t) & 1) * W_BUFBYTES;       // stage t
+      unsigned char* s1 = smem + ((par + t + 1) & 1) * W_BUFBYTES;   // stage t + 1 (t = nk - 1: the NEXT tile's stage 0)
+      half_step(s0, s0 + W_ABYTES, 1, fa, fb);                        // (t, 0) multiplies, (t, 1) is read
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // own DMA of the stage in s1 (and older stores)
+      lds_barrier();                                                  // everyone's; every wave has finished reading s0
+      if (t + 2 < nk) {
+        wstage_glds<TA>(A, p.lda, tm0, (long long)(t + 2) * W_BK, offA, s0, tid);
+        wstage_glds<TB>(B, p.ldb, tn0, (long long)(t + 2) * W_BK, offB, s0 + W_ABYTES, tid);
+      } else if (t + 2 == nk && has_next) {                           // the next tile's first stage rides under this tile's last stage
+        wstage_glds<TA>(A, p.lda, nm0, 0, offA, s0, tid);
+        wstage_glds<TB>(B, p.ldb, nn0, 0, offB, s0 + W_ABYTES, tid);
       }
-      slot ^= 1;
-#pragma unroll
-      for (int ks = 0; ks < 2; ks++) {
-        bf8v fa[4], fb[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-          fa[i] = TA ? wfrag_kmajor(sa, wm * 64 + i * 16, ks, lane) : wfrag_rowmajor(sa, wm * 64 + i * 16, ks, lane);
-          fb[i] = TB ? wfrag_kmajor(sb, wn * 64 + i * 16, ks, lane) : wfrag_rowmajor(sb, wn * 64 + i * 16, ks, lane);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-#pragma unroll
-          for (int j = 0; j < 4; j++)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-      }
+      half_step(s1, s1 + W_ABYTES, 0, fa, fb);                        // (t, 1) multiplies; (t + 1, 0) / (next tile, 0, 0) is read
     }
+    // slot (par + nk - 1) & 1 is free for the epilogue staging; the other holds the next tile's stage 0
 
-    // ---- epilogue: four 64-row f32 chunks through the stage just consumed (slot ^ 1 after the toggle) -> whole 512-byte
-    // row segments in 16-byte lanes.  Image: [64 rows][64 chunks of 16 B], chunk index XORed with (row & 15): the 8-lane
-    // groups of ds_write_b128 (8 consecutive rows, one chunk) and the row reads (32 lanes = 64 chunks of one row) are
-    // conflict-free without padding, so the image is exactly one 64 KiB stage.
-    unsigned char* stg = smem + (nk > 1 ? (slot ^ 1) : 0) * W_BUFBYTES;
+    // ---- epilogue: four 64-row f32 chunks through the free stage -> whole 512-byte row segments in 16-byte lanes.
+    // Image: [64 rows][64 chunks of 16 B], chunk index XORed with (row & 15): conflict-free writes (8-lane groups = 8 rows of
+    // one chunk) and reads (32 lanes = the 64 chunks of one row) without padding: exactly one 64 KiB stage.
+    unsigned char* stg = smem + ((par + nk - 1) & 1) * W_BUFBYTES;
+    int lane_e = lane, tid_e = tid;  // opaque copies: keeps the ~30 loop-invariant staging / output addresses out of the tile
+    asm volatile("" : "+v"(lane_e), "+v"(tid_e));  // loop's live set (hoisted, they spilled 20-26 registers in the k-loop)
+    const int c8e = (tid_e & 31) * 8;
     float bias[8];
 #pragma unroll
-    for (int e = 0; e < 8; e++) bias[e] = p.bias ? p.bias[tn0 + c8 + e] : 0.f;
+    for (int e = 0; e < 8; e++) bias[e] = p.bias ? p.bias[tn0 + c8e + e] : 0.f;
 #pragma unroll
     for (int qq = 0; qq < 4; qq++) {
-      lds_barrier();  // last k-step's reads (qq = 0) / previous chunk's staging reads are done
+      if (qq > 0) lds_barrier();  // previous chunk's staging reads are done (chunk 0: the stage was released by the last mid-barrier)
       if (wm == qq) {
 #pragma unroll
         for (int i = 0; i < 4; i++)
 #pragma unroll
           for (int j = 0; j < 4; j++) {
-            const int row = i * 16 + (lane & 15), chunk = wn * 16 + j * 4 + (lane >> 4);
+            const int row = i * 16 + (lane_e & 15), chunk = wn * 16 + j * 4 + (lane_e >> 4);
             *(f4v*)(stg + row * 1024 + ((chunk ^ (row & 15)) << 4)) = acc[i][j];
           }
       }
       lds_barrier();
 #pragma unroll
       for (int rr = 0; rr < 2; rr++) {
-        const int row = (tid >> 5) + 32 * rr;
-        const int ch = (tid & 31) * 2;
+        const int row = (tid_e >> 5) + 32 * rr;
+        const int ch = (tid_e & 31) * 2;
         const f4v v0 = *(const f4v*)(stg + row * 1024 + ((ch ^ (row & 15)) << 4));
         const f4v v1 = *(const f4v*)(stg + row * 1024 + (((ch + 1) ^ (row & 15)) << 4));
         float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
@@ -168,7 +183,7 @@ __global__ __launch_bounds__(1024, 4) void gemm_bf16_w256(GemmP p) {
         for (int e = 0; e < 8; e++) v[e] = v[e] * p.alpha + bias[e];
         const long long grow = tm0 + qq * 64 + row;
         if (p.resid) {
-          const uint4 rr4 = *(const uint4*)((const bf16raw*)p.resid + grow * p.ldr + tn0 + c8);
+          const uint4 rr4 = *(const uint4*)((const bf16raw*)p.resid + grow * p.ldr + tn0 + c8e);
           const unsigned w[4] = {rr4.x, rr4.y, rr4.z, rr4.w};
 #pragma unroll
           for (int e = 0; e < 4; e++) { v[2 * e] += __uint_as_float(w[e] << 16); v[2 * e + 1] += __uint_as_float(w[e] & 0xffff0000u); }
@@ -178,7 +193,7 @@ __global__ __launch_bounds__(1024, 4) void gemm_bf16_w256(GemmP p) {
           for (int e = 0; e < 8; e++) v[e] = fmaxf(v[e], 0.f);
         }
         if (p.gate) {
-          const uint4 gg = *(const uint4*)((const bf16raw*)p.gate + grow * p.ldg + tn0 + c8);
+          const uint4 gg = *(const uint4*)((const bf16raw*)p.gate + grow * p.ldg + tn0 + c8e);
           const unsigned w[4] = {gg.x, gg.y, gg.z, gg.w};
 #pragma unroll
           for (int e = 0; e < 4; e++) {
@@ -187,7 +202,7 @@ __global__ __launch_bounds__(1024, 4) void gemm_bf16_w256(GemmP p) {
           }
         }
         if (OUTF32) {
-          float* C = (float*)p.C + grow * p.ldc + tn0 + c8;
+          float* C = (float*)p.C + grow * p.ldc + tn0 + c8e;
           if (p.flags & PERO_GEMM_ACCUM) {
             const f4v o0 = *(const f4v*)C, o1 = *(const f4v*)(C + 4);
 #pragma unroll
@@ -198,7 +213,7 @@ __global__ __launch_bounds__(1024, 4) void gemm_bf16_w256(GemmP p) {
         } else {
           uint4 o;
           o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]); o.z = pack2bf(v[4], v[5]); o.w = pack2bf(v[6], v[7]);
-          *(uint4*)((bf16raw*)p.C + grow * p.ldc + tn0 + c8) = o;
+          *(uint4*)((bf16raw*)p.C + grow * p.ldc + tn0 + c8e) = o;
         }
       }
     }
@@ -206,18 +221,24 @@ __global__ __launch_bounds__(1024, 4) void gemm_bf16_w256(GemmP p) {
     T += G;
     tm0 = nm0;
     tn0 = nn0;
-    after_epilogue = nk > 1;
-    if (nk == 1) {  // single k-step tiles: nothing was prefetched (both slots were in use by the epilogue staging)
-      lds_barrier();
-      wstage_glds<TA>(A, p.lda, tm0, 0, offA, smem + slot * W_BUFBYTES, tid);
-      wstage_glds<TB>(B, p.ldb, tn0, 0, offB, smem + slot * W_BUFBYTES + W_ABYTES, tid);
+    par = (par + nk) & 1;     // the slot the next tile's stage 0 was prefetched into
+    lds_barrier();            // every wave is done with the staging slot: it takes the new tile's stage 1
+    wstage_glds<TA>(A, p.lda, tm0, W_BK, offA, stg, tid);
+    wstage_glds<TB>(B, p.ldb, tn0, W_BK, offB, stg + W_ABYTES, tid);
+    // the new tile's first fragments (its stage 0 landed during the last stage).  They are re-read here rather than kept
+    // from the last half step: 32 live fragment registers across the epilogue spilled 40 VGPRs.
+    const unsigned char* f0 = smem + par * W_BUFBYTES;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      fa[i] = TA ? wfrag_kmajor(f0, wm * 64 + i * 16, 0, lane) : wfrag_rowmajor(f0, wm * 64 + i * 16, 0, lane);
+      fb[i] = TB ? wfrag_kmajor(f0 + W_ABYTES, wn * 64 + i * 16, 0, lane) : wfrag_rowmajor(f0 + W_ABYTES, wn * 64 + i * 16, 0, lane);
     }
   }
 }
 
 // Qualifies: one problem (batch 1), no split-K, no atomics, M % 256 == N % 256 == K % 64 == 0.
 bool pero_launch_gemm_w256(const GemmP& p0, long long batch, int k_split, bool ta, bool tb, bool out_f32, hipStream_t st) {
-  if (p0.M % W_BM || p0.N % W_BN || p0.K % W_BK || batch != 1 || k_split > 1 || (p0.flags & PERO_GEMM_ATOMIC)) return false;
+  if (p0.M % W_BM || p0.N % W_BN || p0.K % W_BK || p0.K < 2 * W_BK || batch != 1 || k_split > 1 || (p0.flags & PERO_GEMM_ATOMIC)) return false;
   if (p0.lda >= (1LL << 22) || p0.ldb >= (1LL << 22)) return false;  // 32-bit per-lane byte offsets inside a tile
   static int num_cus = 0;
   if (!num_cus) {

@@ -24,5 +24,24 @@ for ta in (False, True):
             err = (outs[0] - outs[1]).abs().max().item()
             print(f"ta={ta} tb={tb} {sorted(kw)}: max |policy {pol} - default| = {err:.3e}  (|default - f32 matmul| = {(outs[0] - (ref if not kw else outs[0])).abs().max().item():.1e})")
             bad += err > 1e-2
+# many tiles per workgroup (persistent kernels walk several tiles): 44 x 8 = 352 tiles of 256 x 256 on 256 CUs
+M2, N2, K2 = 256 * 44, 2048, 192
+a = (torch.randn(M2, K2, device="cuda") * 0.5).bfloat16(); b = (torch.randn(N2, K2, device="cuda") * 0.5).bfloat16()
+bias = torch.randn(N2, device="cuda"); res = torch.randn(M2, N2, device="cuda").bfloat16()
+outs = []
+for p in (0, pol):
+    _lib.lib().pero_set_option(b"gemm_policy", p)
+    outs.append(ops.gemm(a, b, bias=bias, residual=res, relu=True).float())
+err = (outs[0] - outs[1]).abs().max().item()
+print(f"{M2}x{N2}x{K2} (352 tiles) bias+residual+relu: max |policy {pol} - default| = {err:.3e}")
+bad += err > 1e-2
+bt = (torch.randn(K2, N2, device="cuda") * 0.5).bfloat16()
+outs = []
+for p in (0, pol):
+    _lib.lib().pero_set_option(b"gemm_policy", p)
+    outs.append(ops.gemm(a, bt, trans_b=True).float())
+err = (outs[0] - outs[1]).abs().max().item()
+print(f"{M2}x{N2}x{K2} (352 tiles) NN: max |policy {pol} - default| = {err:.3e}")
+bad += err > 1e-2
 print("FAIL" if bad else "OK")
 sys.exit(1 if bad else 0)

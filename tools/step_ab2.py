@@ -21,16 +21,18 @@ def run(n):
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
 
 run(3)
+FWD_NAMES = {0: "r256", 512: "v256", 513: "w256"}
 res = {}
 for r in range(rounds):
     for side in (True, False):
         for pol in pols:
-            for fwdv in (0, 512):
+            for fwdv in (0, 512, 513):
                 F.SIDE_STREAM_DW = side
-                F.FWD_TILE_FLAGS = fwdv
+                F.FWD_TILE_FLAGS = 512 if fwdv else 0
+                _lib.lib().pero_set_option(b"gemm_persistent", 1 if fwdv == 513 else 0)
                 _lib.lib().pero_set_option(b"gemm_policy", pol)
                 run(1)
                 res.setdefault((side, pol, fwdv), []).append(run(4))
 for (side, pol, fwdv), v in sorted(res.items()):
     v = sorted(v)
-    print(f"side={side!s:5s} policy {pol} fwd-v256={fwdv != 0!s:5s}: ms/step min {v[0]:.3f} median {v[len(v)//2]:.3f}  -> {B / v[len(v)//2] * 1e3:.0f} lines/s")
+    print(f"side={side!s:5s} policy {pol} fwd={FWD_NAMES[fwdv]}: ms/step min {v[0]:.3f} median {v[len(v)//2]:.3f}  -> {B / v[len(v)//2] * 1e3:.0f} lines/s")
