@@ -43,7 +43,7 @@ def linear_fwd(x, w, b, dtype, residual=None, relu=False, out_dtype=None):
 
 FUSE_BIAS_GRAD = True  # bias gradients that are column sums of a dX product's output come out of that product's epilogue
 SIDE_STREAM_DW = True  # weight / bias gradients on a second HIP stream (they are off the backward critical path)
-SIDE_STREAMS = 2       # side streams used round-robin (2 streams + split-K aiming at 256 work items: -1.7 % in-step)
+SIDE_STREAMS = 2       # side streams used round-robin (the library's split-K aims at 512 work items per product)
 _side_streams = {}
 
 

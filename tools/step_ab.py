@@ -39,7 +39,7 @@ for nst, items in ((1, 512), (2, 512), (2, 256), (4, 256), (4, 128), (1, 512), (
     print(f"side streams {nst} split-K items {items}: {run(4):.3f} ms/step")
 F.SIDE_STREAMS = 2
 F._side_streams.clear()
-_lib.lib().pero_set_option(b"splitk_items", 256)
+_lib.lib().pero_set_option(b"splitk_items", 512)
 names = {0: "default r256|s128 +o128at", 9: "p128 sw-pipelined 3 slots", 3: "s128", 4: "o128 all"}
 res = {k: [] for k in names}
 for r in range(rounds):
