@@ -1,5 +1,19 @@
-"""Linear / polynomial warm-up schedule with the interface of the reference's common/lr_scheduler.py
-(class name spelled as there)."""
+"""Warm-up learning-rate schedule with the public surface of the reference's common/lr_scheduler.py
+(`WarmupSchleduler` - spelled as there - with `update_learning_rate(it)` and `current_lr`).
+
+    lr(it) = base_lr * (it / warm) ** order      for 0 <= it <= warm, warm > 0
+           = base_lr                              otherwise
+
+The rule lives in one pure function (`warmup_factor`), so it is testable without an optimizer; the class only writes the
+result into every parameter group, which is how both torch.optim.Adam and optim.FusedAdam read it."""
+
+
+def warmup_factor(iteration, warm_up_iterations, order):
+    """Fraction of the base rate at `iteration` (1.0 once the warm-up is over or when it is disabled)."""
+    disabled = warm_up_iterations is None or order is None or warm_up_iterations <= 0
+    if disabled or iteration > warm_up_iterations:
+        return 1.0
+    return (iteration / warm_up_iterations) ** order
 
 
 class WarmupSchleduler:
@@ -8,21 +22,13 @@ class WarmupSchleduler:
         self.base_lr = base_lr
         self.warm_up_iterations = warm_up_iterations
         self.warm_up_polynomial_order = warm_up_polynomial_order
-        self._last_lr = None
-
-    @property
-    def current_lr(self):
-        return self._last_lr
+        self.current_lr = None  # set by the first update, like the reference's property before any update
 
     def update_learning_rate(self, iteration_count):
-        warm, order = self.warm_up_iterations, self.warm_up_polynomial_order
-        if warm is not None and order is not None and warm > 0 and iteration_count <= warm:
-            lr = ((iteration_count / warm) ** order) * self.base_lr
-        else:
-            lr = self.base_lr
-        self._last_lr = lr
-        for param_group in self.optimizer.param_groups:
-            param_group["lr"] = lr
+        self.current_lr = warmup_factor(iteration_count, self.warm_up_iterations, self.warm_up_polynomial_order) * self.base_lr
+        for group in self.optimizer.param_groups:
+            group["lr"] = self.current_lr
+        return self.current_lr
 
 
 WarmupScheduler = WarmupSchleduler

@@ -1,7 +1,11 @@
-"""joint_embedding_pretraining/batch_operator.py of the reference: two image tensors + four u8 mask tensors to
-the device.  Images stay uint8 NHWC (the /255 + NCHW permute is fused into the HIP front end) unless
-float_images=True."""
+"""Batch operator of the joint-embedding step (surface of the reference's joint_embedding_pretraining/batch_operator.py):
+`prepare_batch(batch)` -> (images1, images2, image_masks1, image_masks2, shift_masks1, shift_masks2) on the device.
+Images stay uint8 NHWC (the /255 and the NCHW permute are fused into the HIP front end) unless `float_images=True`;
+masks stay uint8.  Values may be numpy arrays or device tensors (common/dataloader.BatchCreator)."""
 import torch
+
+_IMAGE_KEYS = ("images", "images2")
+_MASK_KEYS = ("image_masks", "image_masks2", "shift_masks", "shift_masks2")
 
 
 class BatchOperator:
@@ -10,19 +14,17 @@ class BatchOperator:
         self.float_images = float_images
 
     def prepare_batch(self, batch):
-        return (self._prepare_batch_images(batch, "images"), self._prepare_batch_images(batch, "images2"),
-                self._prepare_batch_masks(batch, "image_masks"), self._prepare_batch_masks(batch, "image_masks2"),
-                self._prepare_batch_masks(batch, "shift_masks"), self._prepare_batch_masks(batch, "shift_masks2"))
+        views = [self._prepare_batch_images(batch, key) for key in _IMAGE_KEYS]
+        masks = [self._prepare_batch_masks(batch, key) for key in _MASK_KEYS]
+        return (*views, *masks)
 
     def _prepare_batch_images(self, batch, key="images"):
-        images = torch.as_tensor(batch[key]).to(self.device, non_blocking=True)  # numpy (reference) or device tensor (GPU BatchCreator)
-        if self.float_images:
-            images = images.float().permute(0, 3, 1, 2) / 255.0
-        return images
+        pixels = torch.as_tensor(batch[key]).to(self.device, non_blocking=True)
+        return pixels.float().permute(0, 3, 1, 2) / 255.0 if self.float_images else pixels
 
     def _prepare_batch_masks(self, batch, key="image_masks"):
         return torch.as_tensor(batch[key]).to(self.device, non_blocking=True)
 
     @staticmethod
     def batch_size(batch):
-        return batch["images"].shape[0]
+        return len(batch["images"])
