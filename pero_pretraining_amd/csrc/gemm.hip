@@ -364,11 +364,14 @@ __global__ __launch_bounds__(256) void gemm_generic(GemmP p) {
 //   (16.9), 6 = shape mix of 2/3, 7 = r256, 8 = q256 16-wave 256x256x32 (16.7), 9 = p128 software-pipelined (18.3).
 static int g_gemm_policy = 0;
 static int g_splitk_items = 512;
+static int g_splitk_nearest = 0;    // 1: k-slice count rounded to the nearest multiple of 8 instead of up (faster alone for the
+                                    // 48-tile in_proj gradient, 0.1 ms slower inside the step: tools/splitk_ab.py)
 static int g_gemm_persistent = 1;  // PERO_GEMM_TILE_V products: persistent w256 (epilogue under the next tile's first stage) instead of v256
 int g_pero_splitk_xcd = 1;  // one k-slice per XCD for split-K products (gemm_o.hip)  // work items the automatic split-K aims for (k_split = 0)
 extern "C" int pero_set_option(const char* name, int value) {
   if (name && !strcmp(name, "gemm_policy")) { g_gemm_policy = value; return PERO_OK; }
   if (name && !strcmp(name, "splitk_xcd")) { g_pero_splitk_xcd = value; return PERO_OK; }
+  if (name && !strcmp(name, "splitk_nearest")) { g_splitk_nearest = value; return PERO_OK; }
   if (name && !strcmp(name, "gemm_persistent")) { g_gemm_persistent = value; return PERO_OK; }
   if (name && !strcmp(name, "splitk_items")) { g_splitk_items = value > 0 ? value : 256; return PERO_OK; }
   pero_set_error("pero_set_option: unknown option %s", name ? name : "(null)");
@@ -452,7 +455,7 @@ static int gemm_dispatch(const void* A, const void* B, void* C, const float* bia
       if (ks > K / 512) ks = K / 512;
       if (ks < 1) ks = 1;
       // powers of two (<= 8) or multiples of 8: lets the kernel place one k-slice per XCD
-      if (ks >= 8) ks = ((ks + 7) / 8) * 8;
+      if (ks >= 8) ks = ((ks + (g_splitk_nearest ? 4 : 7)) / 8) * 8;
       else if (ks > 4) ks = 8;
       else if (ks == 3) ks = 4;
       if (ks > K / 64) ks = 1;

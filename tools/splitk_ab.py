@@ -15,10 +15,12 @@ def run(n):
         sched.update_learning_rate(i); trainer.train_step_prepared(*batches[i % 2])
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
 run(3)
-res = {v: [] for v in vals}
+res = {}
 for r in range(3):
     for v in vals:
-        _lib.lib().pero_set_option(b"splitk_items", v)
-        run(1); res[v].append(run(4))
-for v in vals:
-    x = sorted(res[v]); print(f"splitk_items {v:5d}: ms/step min {x[0]:.3f} median {x[1]:.3f}")
+        for nearest in (0, 1):
+            _lib.lib().pero_set_option(b"splitk_items", v)
+            _lib.lib().pero_set_option(b"splitk_nearest", nearest)
+            run(1); res.setdefault((v, nearest), []).append(run(4))
+for (v, nearest), x in sorted(res.items()):
+    x = sorted(x); print(f"splitk_items {v:5d} rounding {'nearest' if nearest else 'up     '}: ms/step min {x[0]:.3f} median {x[1]:.3f}")
