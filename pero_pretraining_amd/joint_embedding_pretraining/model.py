@@ -58,6 +58,9 @@ class MLPHead(torch.nn.Module):
         return y.reshape(N, S, -1)
 
 
+BATCH_VIEWS = True  # encode the two views as one 2N-line batch
+
+
 class JointEmbeddingTransformerEncoder(torch.nn.Module):
     """joint_embedding_pretraining/model.py:33-66."""
 
@@ -66,8 +69,15 @@ class JointEmbeddingTransformerEncoder(torch.nn.Module):
         self.backbone, self.head, self.loss = backbone, head, loss
 
     def forward(self, images1, images2, image_masks1, image_masks2, shift_masks1, shift_masks2):
-        output1 = self.encode(images1)
-        output2 = self.encode(images2)
+        if BATCH_VIEWS and images1.shape == images2.shape and images1.dtype == images2.dtype and images1.is_cuda:
+            # both views through one pass of 2N lines; same weights, same per-view RNG draws
+            n = images1.shape[0]
+            tokens = self.backbone.encode_tokens_views([images1, images2])
+            out = self.head(tokens.view(2 * n, -1, tokens.shape[-1]))
+            output1, output2 = out[:n], out[n:]
+        else:
+            output1 = self.encode(images1)
+            output2 = self.encode(images2)
         loss = self.loss(output1, output2, image_masks1, image_masks2, shift_masks1, shift_masks2)
         return {"output1": output1.detach(), "output2": output2.detach(), **loss}
 

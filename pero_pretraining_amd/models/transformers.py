@@ -145,6 +145,19 @@ class TransformerEncoder(ABC, torch.nn.Module):
         offsets = self.position_model.draw_offsets(x.shape[0], w // self.patch_size[1], x.device)
         return _BackboneFn.apply(self, x, mask, offsets, compute_dtype(), *self._param_list)
 
+    def encode_tokens_views(self, views):
+        """Several equally shaped image batches (the two views of the joint-embedding step) through ONE pass of 2N lines:
+        half the launches and twice the rows per product.  The positional offsets are drawn per view, in view order, with the
+        calls a sequence of separate encodes would make - the same device RNG stream as the reference's two encodes."""
+        if any(v.shape != views[0].shape or v.dtype != views[0].dtype for v in views):
+            raise ValueError("encode_tokens_views: the views must have one shape and dtype")
+        n, seq = views[0].shape[0], views[0].shape[-1 if views[0].dtype != torch.uint8 else 2] // self.patch_size[1]
+        drawn = [self.position_model.draw_offsets(n, seq, views[0].device) for _ in views]
+        offsets = None if any(o is None for o in drawn) else torch.cat(drawn)
+        x = torch.cat(views, dim=0)
+        tokens = _BackboneFn.apply(self, x, None, offsets, compute_dtype(), *self._param_list)
+        return tokens  # (len(views) * N * S, model_dim): view v, line i at rows (v * N + i) * S ...
+
     def mask(self, x, mask):
         m = torch.as_tensor(mask).to(device=x.device, dtype=torch.int64).contiguous()
         if x.dtype != torch.float32 or not x.is_contiguous():
