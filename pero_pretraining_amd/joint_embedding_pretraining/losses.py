@@ -4,7 +4,7 @@ and the per-line similarity matrices run on pero_gemm, the statistics are f32 re
 import torch
 
 from .. import ops
-from .._lib import GEMM_TRANS_A, GEMM_TRANS_B
+from .._lib import GEMM_TILE_V, GEMM_TRANS_A, GEMM_TRANS_B
 from ..precision import compute_dtype
 
 
@@ -41,7 +41,8 @@ class _VICRegFn(torch.autograd.Function):
         ops.colsum(z, cs)
         zc, sumsq = ops.center_cols(z, cs, m)
         cvar, var = ops.vicreg_var(sumsq, m, thr, eps)
-        cov = ops.gemm(zc, zc, trans_a=True, trans_b=True, alpha=1.0 / (m - 1), out_dtype=torch.float32)
+        cov = ops.gemm(zc, zc, trans_a=True, trans_b=True, alpha=1.0 / (m - 1), out_dtype=torch.float32,
+                       extra_flags=GEMM_TILE_V)  # the loss products run alone on the GPU: 256x256x64 tiles
         G, covl = ops.vicreg_cov(cov, cvar, m, wv, wc, dtype)
         loss = wv * var + wi * inv + wc * covl
         ctx.save_for_backward(x2, y2, ix, iy, jx, jy, zc, G)
@@ -54,7 +55,7 @@ class _VICRegFn(torch.autograd.Function):
         x2, y2, ix, iy, jx, jy, zc, G = ctx.saved_tensors
         xs, ys, n1, m, inv_coef, dtype = ctx.meta
         gdev = g.detach().reshape(1).to(torch.float32)
-        dzc = ops.gemm(zc, G)  # (m_pad, D): d(wv*var + wc*cov)/d zc
+        dzc = ops.gemm(zc, G, extra_flags=GEMM_TILE_V)  # (m_pad, D): d(wv*var + wc*cov)/d zc
         dx = torch.zeros_like(x2)
         dy = torch.zeros_like(y2)
         ops.scatter_add_rows_scaled(dzc[:n1], jx, dx, gdev)
