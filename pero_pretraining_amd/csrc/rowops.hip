@@ -99,37 +99,54 @@ __global__ __launch_bounds__(256) void layernorm_bwd_k(const T* dy, const T* x, 
     for (int e = 0; e < 8; e++) { ag[c][e] = 0.f; ab[c][e] = 0.f; ax[c][e] = 0.f; g[c][e] = 0.f; }
     if (col < d) load8<float>(gamma + col, g[c]);
   }
-  for (long long row = (long long)blockIdx.x * 4 + wave; row < rows; row += (long long)gridDim.x * 4) {
-    const float mu = mean[row], rs = rstd[row];
-    float xh[NCH][8], gy[NCH][8];
-    float s1 = 0.f, s2 = 0.f;
+  // two rows per iteration (independent loads and reduction chains in flight: the kernel is latency-, not bandwidth-bound
+  // with one row per wave at a time)
+  const long long stride = (long long)gridDim.x * 4;
+  for (long long row0 = (long long)blockIdx.x * 4 + wave; row0 < rows; row0 += 2 * stride) {
+    const long long rw[2] = {row0, row0 + stride};
+    const bool has[2] = {true, row0 + stride < rows};
+    float mu[2], rs[2], xh[2][NCH][8], gy[2][NCH][8], s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
 #pragma unroll
-    for (int c = 0; c < NCH; c++) {
-      const int col = (c * 64 + lane) * 8;
-      if (col < d) {
-        float xv[8], dv[8];
-        load8<T>(x + row * d + col, xv);
-        load8<T>(dy + row * d + col, dv);
+    for (int u = 0; u < 2; u++) {
+      if (!has[u]) continue;
+      mu[u] = mean[rw[u]]; rs[u] = rstd[rw[u]];
 #pragma unroll
-        for (int e = 0; e < 8; e++) {
-          xh[c][e] = (xv[e] - mu) * rs;
-          gy[c][e] = dv[e] * g[c][e];
-          s1 += gy[c][e];
-          s2 += gy[c][e] * xh[c][e];
-          ag[c][e] += dv[e] * xh[c][e];
-          ab[c][e] += dv[e];
+      for (int c = 0; c < NCH; c++) {
+        const int col = (c * 64 + lane) * 8;
+        if (col < d) {
+          float xv[8], dv[8];
+          load8<T>(x + rw[u] * d + col, xv);
+          load8<T>(dy + rw[u] * d + col, dv);
+#pragma unroll
+          for (int e = 0; e < 8; e++) {
+            xh[u][c][e] = (xv[e] - mu[u]) * rs[u];
+            gy[u][c][e] = dv[e] * g[c][e];
+            s1[u] += gy[u][c][e];
+            s2[u] += gy[u][c][e] * xh[u][c][e];
+            ag[c][e] += dv[e] * xh[u][c][e];
+            ab[c][e] += dv[e];
+          }
         }
       }
     }
-    const float c1 = wave_sum(s1) / (float)d, c2 = wave_sum(s2) / (float)d;
 #pragma unroll
-    for (int c = 0; c < NCH; c++) {
-      const int col = (c * 64 + lane) * 8;
-      if (col < d) {
-        float o[8];
+    for (int o = 32; o > 0; o >>= 1) {  // the four reductions of the two rows interleaved
+      s1[0] += __shfl_xor(s1[0], o, 64); s2[0] += __shfl_xor(s2[0], o, 64);
+      s1[1] += __shfl_xor(s1[1], o, 64); s2[1] += __shfl_xor(s2[1], o, 64);
+    }
 #pragma unroll
-        for (int e = 0; e < 8; e++) { o[e] = rs * (gy[c][e] - c1 - xh[c][e] * c2); ax[c][e] += o[e]; }
-        store8<T>(dx + row * d + col, o);
+    for (int u = 0; u < 2; u++) {
+      if (!has[u]) continue;
+      const float c1 = s1[u] / (float)d, c2 = s2[u] / (float)d;
+#pragma unroll
+      for (int c = 0; c < NCH; c++) {
+        const int col = (c * 64 + lane) * 8;
+        if (col < d) {
+          float o[8];
+#pragma unroll
+          for (int e = 0; e < 8; e++) { o[e] = rs[u] * (gy[u][c][e] - c1 - xh[u][c][e] * c2); ax[c][e] += o[e]; }
+          store8<T>(dx + rw[u] * d + col, o);
+        }
       }
     }
   }
