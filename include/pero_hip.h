@@ -48,7 +48,9 @@ extern "C" {
 
 const char* pero_last_error(void);
 int pero_abi_version(void);
-/* tuning knobs for benchmarking: "gemm_policy" = 0 auto | 1 128-tile persistent | 2 256-tile | 3 128x128x32 */
+/* tuning knobs for benchmarking (A/B of kernel variants; defaults are the measured best): "gemm_policy" (0 = auto, 1..15 =
+ * force one tile-kernel family, table in csrc/gemm.hip), "gemm_persistent" (1), "splitk_items" (512), "splitk_xcd" (1),
+ * "splitk_nearest" (0).  Process-wide; not meant to be changed while products are in flight. */
 int pero_set_option(const char* name, int value);
 
 /* ---- front end ------------------------------------------------------------------------------

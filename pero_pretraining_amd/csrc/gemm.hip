@@ -355,19 +355,25 @@ __global__ __launch_bounds__(256) void gemm_generic(GemmP p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Tile-kernel policy, chosen by interleaved same-process A/B of the WHOLE training step (tools/step_ab.py; isolated
-// hot-cache micro-benchmarks ranked the variants differently, and devices differ by ~10 % between runs):
-//   0 = default: products with a stored output -> gemm_bf16_r256 (256x128x32, 8 waves, two workgroups per CU) when M is a
-//       multiple of 256, else gemm_bf16_s128 (128x128x32, three workgroups per CU); split-K atomic products (weight
-//       gradients) -> gemm_bf16_o128 (128x128x64, one tile per workgroup).  16.3 ms / step at 128 lines.
-//   1 = persistent 128-tile with deferred epilogue (20.7), 2 = 256-tile 8 waves (21.9), 3 = s128 (17.1), 4 = all o128
-//   (16.9), 6 = shape mix of 2/3, 7 = r256, 8 = q256 16-wave 256x256x32 (16.7), 9 = p128 software-pipelined (18.3).
+// Tile-kernel policy, chosen by interleaved same-process A/B of the WHOLE training step (tools/step_ab2.py; isolated
+// hot-cache micro-benchmarks rank the variants differently, and devices differ by a few % between runs):
+//   0 = default:
+//         * products flagged PERO_GEMM_TILE_V (forward pass: they have the GPU to themselves) with >= 192 tiles of 256x256
+//           -> gemm_bf16_w256 (persistent 256x256x64; "gemm_persistent" = 0: gemm_bf16_v256, one tile per workgroup)
+//         * other products with a stored output -> gemm_bf16_r256 (256x128x32, 8 waves, two workgroups per CU) when M is a
+//           multiple of 256, else gemm_bf16_s128 (128x128x32, three workgroups per CU)
+//         * split-K atomic products (weight gradients) -> gemm_bf16_o128 (128x128x64, one tile per workgroup, one k-slice
+//           per XCD), k-slices aimed at "splitk_items" = 512 workgroups
+//   A/B baselines: 1 = persistent 128-tile with deferred epilogue, 2 = 256-tile 8 waves, 3 = s128, 4 = all o128, 6 = shape mix
+//   of 2/3, 7 = r256, 8 = q256 (16-wave 256x256x32), 9 = p128 software-pipelined, 10 = v256 for every stored output,
+//   11 = v256 for K >= 1024, 12 = w256 for every stored output, 13 / 14 = 256x256 / 256x128 split-K tiles for the weight
+//   gradients, 15 = x256 (four waves, 128x128 wave tiles, NT only).  Measurements: DESIGN.md section 8.
 static int g_gemm_policy = 0;
-static int g_splitk_items = 512;
+static int g_splitk_items = 512;     // workgroups the automatic split-K aims for (k_split = 0)
 static int g_splitk_nearest = 0;    // 1: k-slice count rounded to the nearest multiple of 8 instead of up (faster alone for the
                                     // 48-tile in_proj gradient, 0.1 ms slower inside the step: tools/splitk_ab.py)
 static int g_gemm_persistent = 1;  // PERO_GEMM_TILE_V products: persistent w256 (epilogue under the next tile's first stage) instead of v256
-int g_pero_splitk_xcd = 1;  // one k-slice per XCD for split-K products (gemm_o.hip)  // work items the automatic split-K aims for (k_split = 0)
+int g_pero_splitk_xcd = 1;  // one k-slice per XCD for split-K products (gemm_o.hip)
 extern "C" int pero_set_option(const char* name, int value) {
   if (name && !strcmp(name, "gemm_policy")) { g_gemm_policy = value; return PERO_OK; }
   if (name && !strcmp(name, "splitk_xcd")) { g_pero_splitk_xcd = value; return PERO_OK; }
