@@ -41,6 +41,10 @@ extern "C" {
 #define PERO_GEMM_TILE256 128    /* benchmarking: force the 256x256-tile bf16 kernel (when the shape allows) */
 #define PERO_GEMM_TILE_S 256     /* benchmarking: force the 128x128x32 four-workgroups-per-CU kernel */
 #define PERO_GEMM_TILE_V 512     /* prefer the 256x256x64 one-workgroup-per-CU kernel (whole GPU to itself: forward pass) */
+#define PERO_GEMM_ROWDOT 4096   /* bf16 C, N % 128 == 0: `gate` is a bf16 matrix of C's shape that is NOT applied as a gate, and `bias`
+                                 * is an OUTPUT (f32 [M][N/128]): bias[m][b] = sum over columns 128b..128b+127 of C[m][c] * gate[m][c],
+                                 * with C as stored (bf16).  The attention backward's D = rowsum(dO * O) per head, out of the
+                                 * epilogue of the product that writes dO.  No input bias / gate in this mode. */
 #define PERO_GEMM_COLSUM 1024   /* `bias` is an OUTPUT (f32 [N], accumulated atomically): column sums over the M rows of the
                                  * stored result - the bias gradient of the Linear whose output gradient this product
                                  * writes (replaces a separate pero_colsum pass over C).  No input bias in this mode. */
@@ -112,7 +116,9 @@ int pero_softmax_bwd(const void* p, const float* dp, void* ds, int64_t rows, int
  * batched pero_gemm + pero_softmax_* path. */
 int pero_attention_fwd(const void* qkv, void* out, float* lse, int64_t N, int64_t S, int64_t num_heads,
                        int64_t head_dim, int dtype, void* stream);
-/* dqkv (N*S, 3d) from dout (N*S, d); dvec (N*nh, S) f32 scratch (row sums of dout*out).  dbias (f32 [3d], may be null):
+/* dqkv (N*S, 3d) from dout (N*S, d).  dvec (N*S, nh) f32: D[row][head] = sum over the head's 128 columns of dout*out -
+ * computed and stored by the call when `out` is given, or supplied by the caller (out == null; e.g. written by the
+ * PERO_GEMM_ROWDOT epilogue of the product that produced dout).  dbias (f32 [3d], may be null):
  * the column sums of dqkv - in_proj's bias gradient - are ACCUMULATED into it: per-workgroup partial rows from the kernels'
  * staged output tiles into work (f32, 3 * N * nh * (S/128) * 128 elements; required with dbias), then one small reduction. */
 int pero_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* dvec, void* dqkv,
@@ -136,6 +142,9 @@ int pero_masked_ce_bwd(const void* logits, const int64_t* labels, const int64_t*
 /* ---- reductions / elementwise ---------------------------------------------------------------------- */
 /* out[n] += sum_m x[m][n]  (bias gradients); out f32 */
 int pero_colsum(const void* x, float* out, int64_t rows, int64_t cols, int64_t ld, int dtype, void* stream);
+/* out[m][b] = sum over columns 128b..128b+127 of x[m][c] * y[m][c]  (bf16 x, y; the pass PERO_GEMM_ROWDOT fuses) */
+int pero_rowdot_blocks(const void* x, const void* y, float* out, int64_t rows, int64_t cols, int64_t ldx, int64_t ldy,
+                       void* stream);
 /* f32 -> bf16 copy (low-precision weight copies) */
 int pero_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream);
 int pero_cast_bf16_f32(const void* src, float* dst, int64_t n, void* stream);

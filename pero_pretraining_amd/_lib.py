@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libpero_hip.so")
 PERO_F32, PERO_BF16 = 0, 1
 LN_BWD_BLOCKS = 512
 GEMM_RELU, GEMM_ATOMIC, GEMM_ACCUM, GEMM_TRANS_A, GEMM_TRANS_B, GEMM_FORCE_GENERIC = 1, 2, 4, 8, 16, 32
+GEMM_ROWDOT = 4096   # `gate` = second matrix, `bias` = f32 [M][N/128] output of the 128-column-block row dots of the stored result
 GEMM_COLSUM = 1024  # `bias` is an OUTPUT: column sums of the stored result (bias gradient of the upstream Linear)
 GEMM_TILE_V = 512  # prefer the 256x256x64 kernel: products that have the GPU to themselves (forward pass)
 GEMM_TILE128, GEMM_TILE256 = 64, 128
@@ -55,6 +56,7 @@ SIGNATURES = {
     "pero_rownorm_bwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp],
     "pero_ntxent_cols": [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp],
     "pero_vq_ema_update": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _f64, _f64, _vp],
+    "pero_rowdot_blocks": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp],
     "pero_label_rank": [_vp, _i64, _vp, _vp, _i64, _i64, _vp, _i32, _vp, _vp, _i32, _vp],
     "pero_stack_lines": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp],
     "pero_line_masks": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp],

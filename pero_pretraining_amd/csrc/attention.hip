@@ -389,24 +389,35 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_k(const bf16raw* qkv, cons
   attn_glds_half(Kg, ld, smem, wave, lane);
   attn_glds_half(Vg, ld, smem + AT_HALF_BYTES, wave, lane);
 
+  // D[q] = sum_d dO[q][d] O[q][d] (row sums of the output gradient times the output), layout dvec[(line*S + q)*nh + head]:
+  // either already there (out == nullptr: written by the epilogue of the product that produced dO, PERO_GEMM_ROWDOT) or
+  // computed here from the O rows and stored for the dK / dV kernel.
   bf8v qf[8], gf[8];
   float dsum = 0.f;
+  const long long dix = ((long long)line * S + q) * nh + head;
   {
     const bf16raw* qrow = base + (long long)q * ld + 8 * h5;
     const bf16raw* grow = dout + ((long long)line * S + q) * d + head * 128 + 8 * h5;
-    const bf16raw* orow = out + ((long long)line * S + q) * d + head * 128 + 8 * h5;
 #pragma unroll
     for (int ks = 0; ks < 8; ks++) {
       qf[ks] = *(const bf8v*)(qrow + 16 * ks);
       gf[ks] = *(const bf8v*)(grow + 16 * ks);
-      const bf8v of = *(const bf8v*)(orow + 16 * ks);
+    }
+    if (out) {
+      const bf16raw* orow = out + ((long long)line * S + q) * d + head * 128 + 8 * h5;
 #pragma unroll
-      for (int e = 0; e < 8; e++) dsum += (float)gf[ks][e] * (float)of[e];
+      for (int ks = 0; ks < 8; ks++) {
+        const bf8v of = *(const bf8v*)(orow + 16 * ks);
+#pragma unroll
+        for (int e = 0; e < 8; e++) dsum += (float)gf[ks][e] * (float)of[e];
+      }
+      dsum += __shfl_xor(dsum, 32, 64);
+      if (h5 == 0) dvec[dix] = dsum;
+    } else {
+      dsum = dvec[dix];
     }
   }
-  dsum += __shfl_xor(dsum, 32, 64);
   const float lq = lse2[(long long)lh * S + q];
-  if (h5 == 0) dvec[(long long)lh * S + q] = dsum;
 
   f16v dq[4];
 #pragma unroll
@@ -469,7 +480,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv2_k(const bf16raw* qkv, co
   const bf16raw* base = qkv + (long long)line * S * ld + head * 128;
   const bf16raw* Gg = dout + (long long)line * S * d + head * 128;
   const int key = kb * 128 + wave * 32 + r;
-  const float* stat = (tid < 32 ? lse2 : dvec) + (long long)lh * S + (tid & 31);  // threads 0-31: lse2, 32-63: D
+  // row statistics of a 32-query stage: threads 0-31 load lse2[lh][q], threads 32-63 load D[(line*S + q)*nh + head]
+  const float* stat = tid < 32 ? lse2 + (long long)lh * S + tid : dvec + ((long long)line * S + (tid & 31)) * nh + head;
+  const long long stat_step = tid < 32 ? 32 : 32LL * nh;
 
   if (tid < 64) lds_ld[tid] = stat[0];
   attn_glds_img(base + 2 * d + (long long)kb * 128 * ld, ld, vimg, wave, lane);  // this workgroup's V tile, resident
@@ -495,7 +508,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv2_k(const bf16raw* qkv, co
     const float* lds_d = lds_l + 32;
     float nstat = 0.f;
     if (sq + 1 < nsub) {
-      if (tid < 64) nstat = stat[(sq + 1) * 32];  // before the DMA: vmcnt is in-order
+      if (tid < 64) nstat = stat[(sq + 1) * stat_step];  // before the DMA: vmcnt is in-order
       unsigned char* nb = smem + ((sq + 1) & 1) * 2 * AT_SUB_BYTES;
       attn_glds_sub(base + (long long)(sq + 1) * 32 * ld, ld, nb, wave, lane);
       attn_glds_sub(Gg + (long long)(sq + 1) * 32 * d, d, nb + AT_SUB_BYTES, wave, lane);
@@ -538,10 +551,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv2_k(const bf16raw* qkv, co
 extern "C" int pero_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* dvec, void* dqkv,
                                   float* dbias, float* work, int64_t N, int64_t S, int64_t num_heads, int64_t head_dim, int dtype,
                                   void* stream) {
-  PERO_REQUIRE(qkv && out && dout && lse && dvec && dqkv, "pero_attention_bwd: null pointer");
+  PERO_REQUIRE(qkv && dout && lse && dvec && dqkv, "pero_attention_bwd: null pointer");
   PERO_REQUIRE(dtype == PERO_BF16 && head_dim == 128 && S % 128 == 0 && S > 0 && N > 0 && num_heads > 0,
                "pero_attention_bwd: fused kernel needs bf16, head_dim 128, S %% 128 == 0");
-  PERO_REQUIRE(aligned16(qkv) && aligned16(out) && aligned16(dout) && aligned16(dqkv), "pero_attention_bwd: 16-byte alignment");
+  PERO_REQUIRE(aligned16(qkv) && (!out || aligned16(out)) && aligned16(dout) && aligned16(dqkv), "pero_attention_bwd: 16-byte alignment");
   PERO_REQUIRE(!dbias || work, "pero_attention_bwd: dbias needs the partial-sum workspace");
   static bool attr = false;
   if (!attr) {

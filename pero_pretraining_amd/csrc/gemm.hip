@@ -397,12 +397,17 @@ extern "C" int pero_gemm(const void* A, const void* B, void* C, const float* bia
                          float alpha, int flags, int k_split, int in_dtype, int out_dtype, void* stream) {
   bool fused = false;
   if (flags & PERO_GEMM_COLSUM)
-    PERO_REQUIRE(bias && batch == 1 && !(flags & (PERO_GEMM_ATOMIC | PERO_GEMM_ACCUM)),
+    PERO_REQUIRE(bias && batch == 1 && !(flags & (PERO_GEMM_ATOMIC | PERO_GEMM_ACCUM | PERO_GEMM_ROWDOT)),
                  "pero_gemm: PERO_GEMM_COLSUM needs the output pointer in `bias`, one problem, a stored result");
+  if (flags & PERO_GEMM_ROWDOT)
+    PERO_REQUIRE(bias && gate && batch == 1 && out_dtype == PERO_BF16 && N % 128 == 0 && !(flags & (PERO_GEMM_ATOMIC | PERO_GEMM_ACCUM)),
+                 "pero_gemm: PERO_GEMM_ROWDOT needs the output pointer in `bias`, the second matrix in `gate`, bf16 C, N %% 128 == 0");
   const int rc = gemm_dispatch(A, B, C, bias, residual, gate, M, N, K, lda, ldb, ldc, ldr, ldg, batch, batch_inner, sAo, sAi, sBo, sBi,
                                sCo, sCi, alpha, flags, k_split, in_dtype, out_dtype, stream, &fused);
-  if (rc != PERO_OK || !(flags & PERO_GEMM_COLSUM) || fused) return rc;
-  return pero_colsum(C, (float*)bias, M, N, ldc, out_dtype, stream);  // kernels without the fused epilogue: a pass over C
+  if (rc != PERO_OK || !(flags & (PERO_GEMM_COLSUM | PERO_GEMM_ROWDOT)) || fused) return rc;
+  // kernels without the fused epilogue: a pass over C
+  if (flags & PERO_GEMM_ROWDOT) return pero_rowdot_blocks(C, gate, (float*)bias, M, N, ldc, ldg, stream);
+  return pero_colsum(C, (float*)bias, M, N, ldc, out_dtype, stream);
 }
 
 static int gemm_dispatch(const void* A, const void* B, void* C, const float* bias, const void* residual, const void* gate,
@@ -426,9 +431,12 @@ static int gemm_dispatch(const void* A, const void* B, void* C, const float* bia
   hipStream_t st = (hipStream_t)stream;
   // PERO_GEMM_COLSUM: only the r256 / v256 epilogues accumulate the column sums (`pc`); every other kernel gets `p`
   // without the flag and without the (output) bias pointer, and pero_gemm runs pero_colsum over C afterwards.
-  const bool want_cs = flags & PERO_GEMM_COLSUM;
+  // PERO_GEMM_ROWDOT is handled the same way (r256 only): `pc` keeps flag, gate and output pointer, `p` loses all three.
+  const bool want_cs = flags & (PERO_GEMM_COLSUM | PERO_GEMM_ROWDOT);
+  const bool want_rd = flags & PERO_GEMM_ROWDOT;
+  const int cs_bits = flags & (PERO_GEMM_COLSUM | PERO_GEMM_ROWDOT);
   GemmP pc = p;
-  if (want_cs) { flags &= ~PERO_GEMM_COLSUM; p.flags = flags; p.bias = nullptr; }
+  if (want_cs) { flags &= ~(PERO_GEMM_COLSUM | PERO_GEMM_ROWDOT); p.flags = flags; p.bias = nullptr; if (want_rd) p.gate = nullptr; }
 
   const int esz_o = out_dtype == PERO_F32 ? 4 : 2;
   bool fast = in_dtype == PERO_BF16 && !(flags & 32) && M % T_BM == 0 && N % T_BN == 0 && K % T_BK == 0 &&
@@ -441,7 +449,7 @@ static int gemm_dispatch(const void* A, const void* B, void* C, const float* bia
     else if (g_gemm_policy == 2) flags |= PERO_GEMM_TILE256;
     else if (g_gemm_policy == 3) flags |= PERO_GEMM_TILE_S;
     p.flags = flags;
-    pc.flags = flags | (want_cs ? PERO_GEMM_COLSUM : 0);
+    pc.flags = flags | cs_bits;
   }
   const bool forced0 = flags & (PERO_GEMM_TILE128 | PERO_GEMM_TILE256 | PERO_GEMM_TILE_S);
   if (fast) {
@@ -517,7 +525,7 @@ static int gemm_dispatch(const void* A, const void* B, void* C, const float* bia
       PERO_CHECK_LAUNCH("pero_gemm(w256)");
       return PERO_OK;
     }
-    if ((g_gemm_policy == 10 || g_gemm_policy == 12 || (g_gemm_policy == 11 && K >= 1024) || (g_gemm_policy == 0 && (flags & PERO_GEMM_TILE_V) && t256 >= 192)) && !forced0 && !atomic && pero_launch_gemm_v256(want_cs ? pc : p, batch, k_split, ta, tb, out_dtype == PERO_F32, st)) {
+    if ((g_gemm_policy == 10 || g_gemm_policy == 12 || (g_gemm_policy == 11 && K >= 1024) || (g_gemm_policy == 0 && (flags & PERO_GEMM_TILE_V) && t256 >= 192)) && !forced0 && !atomic && !want_rd && pero_launch_gemm_v256(want_cs ? pc : p, batch, k_split, ta, tb, out_dtype == PERO_F32, st)) {
       *colsum_fused = want_cs;
       PERO_CHECK_LAUNCH("pero_gemm(v256)");
       return PERO_OK;

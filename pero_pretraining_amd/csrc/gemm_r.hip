@@ -159,8 +159,9 @@ __global__ __launch_bounds__(512, 4) void gemm_bf16_r256(GemmP p, int ks_xcd) {
   const int c8 = (tid & 15) * 8;
   float bias[8];
   const bool colsum = p.flags & PERO_GEMM_COLSUM;  // p.bias is then an OUTPUT (column sums of the stored result)
+  const bool rowdot = p.flags & PERO_GEMM_ROWDOT;  // p.bias is an OUTPUT [M][N/128], p.gate the matrix the rows are dotted with
 #pragma unroll
-  for (int e = 0; e < 8; e++) bias[e] = (p.bias && !colsum) ? p.bias[tn0 + c8 + e] : 0.f;
+  for (int e = 0; e < 8; e++) bias[e] = (p.bias && !colsum && !rowdot) ? p.bias[tn0 + c8 + e] : 0.f;
   float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int half = 0; half < 4; half++) {
@@ -206,7 +207,20 @@ __global__ __launch_bounds__(512, 4) void gemm_bf16_r256(GemmP p, int ks_xcd) {
 #pragma unroll
         for (int e = 0; e < 8; e++) v[e] = fmaxf(v[e], 0.f);
       }
-      if (p.gate) {
+      if (rowdot) {
+        // this thread's 8 columns of row `grow` (rounded to bf16 as they are stored) times the same columns of p.gate; the 16
+        // lanes that share the row (tid & 15 = column group, 128 columns = one block) meet by shuffles
+        const uint4 gg = *(const uint4*)((const bf16raw*)p.gate + coff + grow * p.ldg + tn0 + c8);
+        const unsigned w[4] = {gg.x, gg.y, gg.z, gg.w};
+        float dot = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          dot += bf2f(f2bf(v[2 * e])) * __uint_as_float(w[e] << 16);
+          dot += bf2f(f2bf(v[2 * e + 1])) * __uint_as_float(w[e] & 0xffff0000u);
+        }
+        dot += __shfl_xor(dot, 1, 64); dot += __shfl_xor(dot, 2, 64); dot += __shfl_xor(dot, 4, 64); dot += __shfl_xor(dot, 8, 64);
+        if ((tid & 15) == 0) ((float*)p.bias)[grow * (p.N >> 7) + (tn0 >> 7)] = dot;
+      } else if (p.gate) {
         const uint4 gg = *(const uint4*)((const bf16raw*)p.gate + coff + grow * p.ldg + tn0 + c8);
         const unsigned w[4] = {gg.x, gg.y, gg.z, gg.w};
 #pragma unroll

@@ -320,3 +320,27 @@ extern "C" int pero_scatter_add_rows(const void* src, const int64_t* index, void
   PERO_CHECK_LAUNCH("pero_scatter_add_rows");
   return PERO_OK;
 }
+
+// out[m][b] = sum over columns 128b .. 128b+127 of x[m][c] * y[m][c]  (bf16): the attention backward's D per head when the
+// product that writes dO ran on a kernel without the PERO_GEMM_ROWDOT epilogue.  One wave per (row, block): 2 columns per lane.
+__global__ __launch_bounds__(256) void rowdot_blocks_k(const bf16raw* x, const bf16raw* y, float* out, long long rows, int nblk,
+                                                      long long ldx, long long ldy) {
+  const long long item = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (item >= rows * nblk) return;
+  const long long row = item / nblk;
+  const int b = (int)(item - row * nblk), lane = threadIdx.x & 63;
+  const unsigned xv = *(const unsigned*)(x + row * ldx + 128 * b + 2 * lane);
+  const unsigned yv = *(const unsigned*)(y + row * ldy + 128 * b + 2 * lane);
+  float s = __uint_as_float(xv << 16) * __uint_as_float(yv << 16) + __uint_as_float(xv & 0xffff0000u) * __uint_as_float(yv & 0xffff0000u);
+  s = wave_sum(s);
+  if (lane == 0) out[item] = s;
+}
+extern "C" int pero_rowdot_blocks(const void* x, const void* y, float* out, int64_t rows, int64_t cols, int64_t ldx, int64_t ldy,
+                                  void* stream) {
+  PERO_REQUIRE(x && y && out && rows > 0 && cols > 0 && cols % 128 == 0 && ldx % 2 == 0 && ldy % 2 == 0, "pero_rowdot_blocks: bad arguments");
+  const long long items = rows * (cols / 128);
+  hipLaunchKernelGGL(rowdot_blocks_k, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const bf16raw*)x,
+                     (const bf16raw*)y, out, (long long)rows, (int)(cols / 128), (long long)ldx, (long long)ldy);
+  PERO_CHECK_LAUNCH("pero_rowdot_blocks");
+  return PERO_OK;
+}

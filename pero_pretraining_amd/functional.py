@@ -41,6 +41,7 @@ def linear_fwd(x, w, b, dtype, residual=None, relu=False, out_dtype=None):
                     out_dtype=out_dtype, extra_flags=FWD_TILE_FLAGS)
 
 
+FUSE_ROWDOT = True     # attention backward's D = rowsum(dO * O) from the epilogue of the out-projection's dX product
 FUSE_BIAS_GRAD = True  # bias gradients that are column sums of a dX product's output come out of that product's epilogue
 SIDE_STREAM_DW = True  # weight / bias gradients on a second HIP stream (they are off the backward critical path)
 SIDE_STREAMS = 2       # side streams used round-robin (the library's split-K aims at 512 work items per product)
@@ -104,10 +105,12 @@ class SideStream:
         self.keep = []
 
 
-def linear_bwd(dy, x, w, b, dtype, need_dx=True, gate=None, residual=None, bias_grad_done=False, side=None, dx_colsum_into=None):
+def linear_bwd(dy, x, w, b, dtype, need_dx=True, gate=None, residual=None, bias_grad_done=False, side=None, dx_colsum_into=None,
+               dx_rowdot=None):
     """dy (M,N), x (M,K), w (N,K).  Accumulates dW (+db) into .grad; returns dx = dy @ W (+residual)(*gate>0).
     dx_colsum_into: f32 [K] that receives the column sums of dx (the bias gradient of the Linear that produced x), fused
-    into the dX product's epilogue."""
+    into the dX product's epilogue.  dx_rowdot = (y, out): per-128-column-block row dots of dx with y (the attention backward's D
+    when dx is the attention output's gradient and y the attention output), same epilogue."""
     def grads():
         if w.requires_grad:
             ops.gemm(dy, x, out=ensure_grad(w).view(w.shape[0], -1), trans_a=True, trans_b=True, atomic=True, k_split=0)
@@ -123,7 +126,7 @@ def linear_bwd(dy, x, w, b, dtype, need_dx=True, gate=None, residual=None, bias_
     if not need_dx:
         return None
     return ops.gemm(dy, lowp.weight(w, dtype).view(w.shape[0], -1), trans_b=True, residual=residual, gate=gate,
-                    colsum_into=dx_colsum_into)
+                    colsum_into=dx_colsum_into, rowdot=dx_rowdot)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -197,12 +200,18 @@ def layer_bwd(dt2, L, saved, n, s, h, dtype, side=None):
     dt1 = linear_bwd(dpre1, t1, L.linear1.weight, L.linear1.bias, dtype, residual=dy2, side=side, bias_grad_done=fuse_b1)
     dy1 = ops.layernorm_bwd(dt1, y1, mean1, rstd1, L.norm1.weight.detach(), ensure_grad(L.norm1.weight),
                             ensure_grad(L.norm1.bias), ensure_grad(at.out_proj.bias))
-    da = linear_bwd(dy1, a, at.out_proj.weight, at.out_proj.bias, dtype, bias_grad_done=True, side=side)
+    fused_attn = p.dim() == 2
+    dvec = None
+    if fused_attn and FUSE_ROWDOT and a.shape[1] % 128 == 0:
+        # D = rowsum(dO * O) per head out of the epilogue of the product that writes dO (the dQ kernel then skips the O rows)
+        dvec = torch.empty((a.shape[0], a.shape[1] // 128), device=a.device, dtype=torch.float32)
+    da = linear_bwd(dy1, a, at.out_proj.weight, at.out_proj.bias, dtype, bias_grad_done=True, side=side,
+                    dx_rowdot=(a, dvec) if dvec is not None else None)
     fuse_bq = False
     if p.dim() == 2:
         # in_proj's bias gradient = column sums of dqkv: out of the attention kernels' staged output tiles
         fuse_bq = FUSE_BIAS_GRAD and at.in_proj_bias is not None and at.in_proj_bias.requires_grad
-        dqkv = ops.attention_bwd_fused(qkv, a, da, p, n, s, h, dbias=ensure_grad(at.in_proj_bias) if fuse_bq else None)
+        dqkv = ops.attention_bwd_fused(qkv, a, da, p, n, s, h, dbias=ensure_grad(at.in_proj_bias) if fuse_bq else None, dvec=dvec)
     else:
         dqkv = attention_bwd(qkv, p, da, n, s, h)
     return linear_bwd(dqkv, t, at.in_proj_weight, at.in_proj_bias, dtype, residual=dy1, side=side, bias_grad_done=fuse_bq)

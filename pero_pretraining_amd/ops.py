@@ -3,7 +3,7 @@ current HIP stream; all arithmetic happens in the hand-written kernels.  No CPU 
 import torch
 
 from . import _lib
-from ._lib import (GEMM_ACCUM, GEMM_ATOMIC, GEMM_COLSUM, GEMM_FORCE_GENERIC, GEMM_RELU, GEMM_TRANS_A, GEMM_TRANS_B,
+from ._lib import (GEMM_ACCUM, GEMM_ATOMIC, GEMM_COLSUM, GEMM_FORCE_GENERIC, GEMM_ROWDOT, GEMM_RELU, GEMM_TRANS_A, GEMM_TRANS_B,
                    PERO_BF16, PERO_F32, call)
 
 
@@ -56,10 +56,11 @@ def gemm_raw(A, B, C, M, N, K, lda, ldb, ldc, *, bias=None, residual=None, gate=
 
 def gemm(a, b, out=None, *, bias=None, residual=None, gate=None, trans_a=False, trans_b=False, relu=False,
          alpha=1.0, out_dtype=None, atomic=False, accum=False, k_split=1, force_generic=False, extra_flags=0,
-         colsum_into=None):
+         colsum_into=None, rowdot=None):
     """out[M,N] = alpha * op(a) @ op(b)^T ...   a: [M,K] ([K,M] if trans_a); b: [N,K] ([K,N] if trans_b).
     Row-strided 2-D views are fine (unit stride in the last dim).  colsum_into (f32 [N]): the column sums of the stored
-    result are accumulated into it (PERO_GEMM_COLSUM; no input bias in that mode)."""
+    result are accumulated into it (PERO_GEMM_COLSUM; no input bias in that mode).  rowdot = (y, out): out (f32 [M][N/128])
+    receives, per 128-column block, the row dots of the stored bf16 result with y (bf16 [M][N]) - PERO_GEMM_ROWDOT."""
     assert a.dim() == 2 and b.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1
     M, K = (a.shape[1], a.shape[0]) if trans_a else a.shape
     N, Kb = (b.shape[1], b.shape[0]) if trans_b else b.shape
@@ -72,6 +73,11 @@ def gemm(a, b, out=None, *, bias=None, residual=None, gate=None, trans_a=False, 
     if colsum_into is not None:
         assert bias is None and colsum_into.dtype == torch.float32 and colsum_into.numel() == N
         bias, flags = colsum_into, flags | GEMM_COLSUM
+    if rowdot is not None:
+        y, dots = rowdot
+        assert bias is None and gate is None and N % 128 == 0 and y.shape == (M, N) and y.stride(1) == 1
+        assert dots.dtype == torch.float32 and dots.numel() == M * (N // 128) and dots.is_contiguous()
+        bias, gate, flags = dots, y, flags | GEMM_ROWDOT
     gemm_raw(a, b, out, M, N, K, a.stride(0), b.stride(0), out.stride(0), bias=bias, residual=residual, gate=gate,
              ldr=residual.stride(0) if residual is not None else 0, ldg=gate.stride(0) if gate is not None else 0,
              alpha=alpha, flags=flags, k_split=k_split)
@@ -125,11 +131,15 @@ def attention_fwd_fused(qkv, n, s, h):
     return out, lse
 
 
-def attention_bwd_fused(qkv, out, dout, lse, n, s, h, dbias=None):
-    """dbias (f32 [3d], optional): in_proj's bias gradient (column sums of dqkv) is accumulated into it by the kernels."""
+def attention_bwd_fused(qkv, out, dout, lse, n, s, h, dbias=None, dvec=None):
+    """dbias (f32 [3d], optional): in_proj's bias gradient (column sums of dqkv) is accumulated into it by the kernels.
+    dvec (f32 [n*s][h], optional): D = per-head row sums of dout * out, already computed (then `out` is not read)."""
     d = qkv.shape[1] // 3
     dqkv = torch.empty_like(qkv)
-    dvec = torch.empty((n * h, s), device=qkv.device, dtype=torch.float32)
+    if dvec is None:
+        dvec = torch.empty((n * s, h), device=qkv.device, dtype=torch.float32)
+    else:
+        out = None
     work = torch.empty(3 * n * h * (s // 128) * 128, device=qkv.device, dtype=torch.float32) if dbias is not None else None
     call("pero_attention_bwd", ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(dvec), ptr(dqkv), ptr(dbias), ptr(work), n, s, h, d // h,
          dt(qkv), stream())

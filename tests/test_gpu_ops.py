@@ -495,3 +495,20 @@ def test_patches_divide_every_byte_value_exactly():
     got16 = ops.patches_from_u8(img.cuda(), None, None, 8, torch.bfloat16, pitch=1024)
     assert torch.equal(got16[:, :960].cpu(), ref_rows.bfloat16()) and float(got16[:, 960:].abs().max()) == 0.0
     assert set(img.reshape(-1).tolist()) == set(range(256))
+
+
+@pytest.mark.parametrize("M,N,K", [(512, 256, 128), (256, 512, 64), (192, 128, 72)])
+def test_gemm_fused_row_dots(M, N, K):
+    """PERO_GEMM_ROWDOT: per-128-column-block row dots of the stored result with a second matrix (the attention backward's D out
+    of the epilogue of the product that writes dO), tile kernel and fallback pass."""
+    from pero_pretraining_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(M * 3 + N + K)
+    dy = (torch.randn(M, K, device="cuda", generator=g) * 0.5).bfloat16()
+    w = (torch.randn(K, N, device="cuda", generator=g) * 0.5).bfloat16()
+    y = torch.randn(M, N, device="cuda", generator=g).bfloat16()
+    dots = torch.full((M, N // 128), 7.0, device="cuda")
+    out = ops.gemm(dy, w, trans_b=True, rowdot=(y, dots))
+    ref = ops.gemm(dy, w, trans_b=True)
+    assert torch.equal(out, ref)
+    want = (ref.float() * y.float()).view(M, N // 128, 128).sum(-1)
+    assert float((dots - want).abs().max()) <= 1e-3 * max(1.0, float(want.abs().max()))
