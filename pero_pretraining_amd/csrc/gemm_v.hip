@@ -11,7 +11,7 @@
 #define V_ABYTES (256 * 64 * 2)      // 32 KiB operand tile
 #define V_BUFBYTES (2 * V_ABYTES)    // 64 KiB per stage
 #define V_EPI_PITCH 1040             // f32 staging pitch (256 * 4 + 16)
-#define V_LDS_BYTES (2 * V_BUFBYTES) // 128 KiB (>= 64-row f32 staging of 66560 B)
+#define V_LDS_BYTES (5 * V_ABYTES)   // 160 KiB: three A slots + two B slots (>= 64-row f32 staging of 66560 B)
 
 // K-contiguous image [256 rows][64 k] = 128-byte rows, 16-byte chunk index XORed with (row & 7): conflict-free for the
 // real ds_read_b128 lane groups ({0-3,12-15,20-27}, ...: rows {0-3,12-15} with chunk c and rows {4-11} with chunk c^1).
@@ -105,33 +105,42 @@ __global__ __launch_bounds__(1024, 4) void gemm_bf16_v256(GemmP p, int ks_xcd) {
       __builtin_amdgcn_sched_group_barrier(0x100, TA ? 2 : 1, 0);        // then the read(s) that refill fa[i]
     }
   };
+  // LDS: THREE slots for the A operand (the streamed one: activations / gradients from HBM) and two for B (weights: L2
+  // hits) = 160 KiB.  At the mid-stage barrier of stage t the wave issues B(t+2) and then A(t+3), and waits with vmcnt(2):
+  // the two A instructions issued one barrier earlier may still be in flight - A gets a window of TWO stages to land, B
+  // of one.  (With two slots each, every DMA had exactly one stage: the waves spent ~30 % of their cycles in that wait.)
+  unsigned char* const abase = smem;
+  unsigned char* const bbase = smem + 3 * V_ABYTES;
   bf8v fa[4], fb[4];
   if (nk > 0) {
-    vstage_glds<TA>(A, p.lda, tm0, kbeg, smem, tid);
-    vstage_glds<TB>(B, p.ldb, tn0, kbeg, smem + V_ABYTES, tid);
+    vstage_glds<TA>(A, p.lda, tm0, kbeg, abase, tid);
+    vstage_glds<TB>(B, p.ldb, tn0, kbeg, bbase, tid);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_barrier();
     if (nk > 1) {
-      vstage_glds<TA>(A, p.lda, tm0, kbeg + V_BK, smem + V_BUFBYTES, tid);
-      vstage_glds<TB>(B, p.ldb, tn0, kbeg + V_BK, smem + V_BUFBYTES + V_ABYTES, tid);
+      vstage_glds<TB>(B, p.ldb, tn0, kbeg + V_BK, bbase + V_ABYTES, tid);
+      vstage_glds<TA>(A, p.lda, tm0, kbeg + V_BK, abase + V_ABYTES, tid);
     }
+    if (nk > 2) vstage_glds<TA>(A, p.lda, tm0, kbeg + 2 * V_BK, abase + 2 * V_ABYTES, tid);
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      fa[i] = TA ? vfrag_kmajor(smem, wm * 64 + i * 16, 0, lane) : vfrag_rowmajor(smem, wm * 64 + i * 16, 0, lane);
-      fb[i] = TB ? vfrag_kmajor(smem + V_ABYTES, wn * 64 + i * 16, 0, lane) : vfrag_rowmajor(smem + V_ABYTES, wn * 64 + i * 16, 0, lane);
+      fa[i] = TA ? vfrag_kmajor(abase, wm * 64 + i * 16, 0, lane) : vfrag_rowmajor(abase, wm * 64 + i * 16, 0, lane);
+      fb[i] = TB ? vfrag_kmajor(bbase, wn * 64 + i * 16, 0, lane) : vfrag_rowmajor(bbase, wn * 64 + i * 16, 0, lane);
     }
   }
+  int a0 = 0;  // A slot of stage t (t % 3)
   for (int t = 0; t < nk; t++) {
-    unsigned char* s0 = smem + (t & 1) * V_BUFBYTES;         // stage t
-    unsigned char* s1 = smem + ((t + 1) & 1) * V_BUFBYTES;   // stage t + 1
-    half_step(s0, s0 + V_ABYTES, 1, fa, fb);                  // (t, 0) multiplies, (t, 1) is read
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // own DMA of stage t + 1
+    const int a1 = a0 == 2 ? 0 : a0 + 1;
+    unsigned char* sa0 = abase + a0 * V_ABYTES;
+    unsigned char* sb0 = bbase + (t & 1) * V_ABYTES;
+    half_step(sa0, sb0, 1, fa, fb);                           // (t, 0) multiplies, (t, 1) is read
+    if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");  // own A(t+1), B(t+1) landed; A(t+2) (newest) may fly
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_barrier();                                            // everyone's; every wave has finished reading stage t
-    if (t + 2 < nk) {
-      vstage_glds<TA>(A, p.lda, tm0, kbeg + (long long)(t + 2) * V_BK, s0, tid);
-      vstage_glds<TB>(B, p.ldb, tn0, kbeg + (long long)(t + 2) * V_BK, s0 + V_ABYTES, tid);
-    }
-    half_step(s1, s1 + V_ABYTES, 0, fa, fb);                  // (t, 1) multiplies, (t + 1, 0) is read (unused garbage after the last stage)
+    if (t + 2 < nk) vstage_glds<TB>(B, p.ldb, tn0, kbeg + (long long)(t + 2) * V_BK, sb0, tid);
+    if (t + 3 < nk) vstage_glds<TA>(A, p.lda, tm0, kbeg + (long long)(t + 3) * V_BK, sa0, tid);
+    half_step(abase + a1 * V_ABYTES, bbase + ((t + 1) & 1) * V_ABYTES, 0, fa, fb);  // (t, 1) multiplies, (t + 1, 0) is read
+    a0 = a1;
   }
 
   // ---- epilogue: four 64-row chunks through LDS -> whole 512-byte row segments (16-byte lanes)

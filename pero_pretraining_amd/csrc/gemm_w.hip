@@ -13,7 +13,7 @@
 #define W_BK 64
 #define W_ABYTES (256 * 64 * 2)      // 32 KiB operand tile
 #define W_BUFBYTES (2 * W_ABYTES)    // 64 KiB per stage
-#define W_LDS_BYTES (2 * W_BUFBYTES) // 128 KiB; the f32 epilogue staging (64 rows x 1 KiB, XOR-swizzled, no padding) is one stage
+#define W_LDS_BYTES (5 * W_ABYTES)   // 160 KiB: three A slots + two B slots; the f32 epilogue staging (64 rows x 1 KiB, XOR-swizzled) takes one of each
 
 // K-contiguous image [256 rows][64 k] = 128-byte rows, 16-byte chunk index XORed with (row & 7): conflict-free for the
 // real ds_read_b128 lane groups ({0-3,12-15,20-27}, ...: rows {0-3,12-15} with chunk c and rows {4-11} with chunk c^1).
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(1024, 4) void gemm_bf16_w256(GemmP p) {
   const int q8 = nt >> 3, r8 = nt & 7;
   const bf16raw* A = (const bf16raw*)p.A;
   const bf16raw* B = (const bf16raw*)p.B;
-  const int nk = (int)(p.K / W_BK);  // >= 2 (launcher)
+  const int nk = (int)(p.K / W_BK);  // >= 3 (launcher)
   const int c8 = (tid & 31) * 8;
   const unsigned offA = wlane_off<TA>(p.lda, tid), offB = wlane_off<TB>(p.ldb, tid);
 
@@ -108,19 +108,26 @@ __global__ __launch_bounds__(1024, 4) void gemm_bf16_w256(GemmP p) {
     }
   };
 
-  // first tile: stage 0 -> slot 0, stage 1 -> slot 1, fragments of (0, ks 0)
-  int par = 0;  // slot of the current tile's stage 0
+  // LDS ring: THREE 32 KiB slots for the A operand (streamed from HBM) + TWO for B (weights: L2 hits) = 160 KiB.  Stage g of
+  // the (tile, k-step) stream lives in A slot g % 3 and B slot g & 1.  At the mid-stage barrier of stage g the workgroup
+  // issues B(g + 2) and then A(g + 3), and waits with vmcnt(2): A(g + 2) - the newest two DMA instructions - may still be
+  // in flight, so A has a window of TWO stages to land, B of one.  At a tile's last stage the two freed slots take the
+  // epilogue staging instead (rows 0-31 in the A slot, 32-63 in the B slot) and the issue is made up after the epilogue.
+  unsigned char* const abase = smem;
+  unsigned char* const bbase = smem + 3 * W_ABYTES;
+  int a0 = 0, b0 = 0;  // slots of the current stage
   bf8v fa[4], fb[4];
-  wstage_glds<TA>(A, p.lda, tm0, 0, offA, smem, tid);
-  wstage_glds<TB>(B, p.ldb, tn0, 0, offB, smem + W_ABYTES, tid);
+  wstage_glds<TA>(A, p.lda, tm0, 0, offA, abase, tid);
+  wstage_glds<TB>(B, p.ldb, tn0, 0, offB, bbase, tid);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   lds_barrier();
-  wstage_glds<TA>(A, p.lda, tm0, W_BK, offA, smem + W_BUFBYTES, tid);
-  wstage_glds<TB>(B, p.ldb, tn0, W_BK, offB, smem + W_BUFBYTES + W_ABYTES, tid);
+  wstage_glds<TB>(B, p.ldb, tn0, W_BK, offB, bbase + W_ABYTES, tid);
+  wstage_glds<TA>(A, p.lda, tm0, W_BK, offA, abase + W_ABYTES, tid);
+  wstage_glds<TA>(A, p.lda, tm0, 2 * W_BK, offA, abase + 2 * W_ABYTES, tid);
 #pragma unroll
   for (int i = 0; i < 4; i++) {
-    fa[i] = TA ? wfrag_kmajor(smem, wm * 64 + i * 16, 0, lane) : wfrag_rowmajor(smem, wm * 64 + i * 16, 0, lane);
-    fb[i] = TB ? wfrag_kmajor(smem + W_ABYTES, wn * 64 + i * 16, 0, lane) : wfrag_rowmajor(smem + W_ABYTES, wn * 64 + i * 16, 0, lane);
+    fa[i] = TA ? wfrag_kmajor(abase, wm * 64 + i * 16, 0, lane) : wfrag_rowmajor(abase, wm * 64 + i * 16, 0, lane);
+    fb[i] = TB ? wfrag_kmajor(bbase, wn * 64 + i * 16, 0, lane) : wfrag_rowmajor(bbase, wn * 64 + i * 16, 0, lane);
   }
 
   for (;;) {
@@ -133,26 +140,30 @@ __global__ __launch_bounds__(1024, 4) void gemm_bf16_w256(GemmP p) {
       for (int j = 0; j < 4; j++) acc[i][j] = (f4v){0.f, 0.f, 0.f, 0.f};
 
     for (int t = 0; t < nk; t++) {
-      unsigned char* s0 = smem + ((par + t) & 1) * W_BUFBYTES;       // stage t
-      unsigned char* s1 = smem + ((par + t + 1) & 1) * W_BUFBYTES;   // stage t + 1 (t = nk - 1: the NEXT tile's stage 0)
-      half_step(s0, s0 + W_ABYTES, 1, fa, fb);                        // (t, 0) multiplies, (t, 1) is read
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // own DMA of the stage in s1 (and older stores)
-      lds_barrier();                                                  // everyone's; every wave has finished reading s0
-      if (t + 2 < nk) {
-        wstage_glds<TA>(A, p.lda, tm0, (long long)(t + 2) * W_BK, offA, s0, tid);
-        wstage_glds<TB>(B, p.ldb, tn0, (long long)(t + 2) * W_BK, offB, s0 + W_ABYTES, tid);
-      } else if (t + 2 == nk && has_next) {                           // the next tile's first stage rides under this tile's last stage
-        wstage_glds<TA>(A, p.lda, nm0, 0, offA, s0, tid);
-        wstage_glds<TB>(B, p.ldb, nn0, 0, offB, s0 + W_ABYTES, tid);
+      const int a1 = a0 == 2 ? 0 : a0 + 1;
+      unsigned char* sa0 = abase + a0 * W_ABYTES;
+      unsigned char* sb0 = bbase + b0 * W_ABYTES;
+      half_step(sa0, sb0, 1, fa, fb);                                 // (t, 0) multiplies, (t, 1) is read
+      if (t + 2 < nk || has_next) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");  // own A, B of the next stage (and older
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // stores) are done; A two stages ahead may fly
+      lds_barrier();                                                  // everyone's; every wave has finished reading stage t
+      if (t + 1 < nk) {                                               // (last stage: the freed slots stage the epilogue)
+        if (t + 2 < nk) wstage_glds<TB>(B, p.ldb, tn0, (long long)(t + 2) * W_BK, offB, sb0, tid);
+        else if (has_next) wstage_glds<TB>(B, p.ldb, nn0, 0, offB, sb0, tid);
+        if (t + 3 < nk) wstage_glds<TA>(A, p.lda, tm0, (long long)(t + 3) * W_BK, offA, sa0, tid);
+        else if (has_next) wstage_glds<TA>(A, p.lda, nm0, (long long)(t + 3 - nk) * W_BK, offA, sa0, tid);
       }
-      half_step(s1, s1 + W_ABYTES, 0, fa, fb);                        // (t, 1) multiplies; (t + 1, 0) / (next tile, 0, 0) is read
+      half_step(abase + a1 * W_ABYTES, bbase + (b0 ^ 1) * W_ABYTES, 0, fa, fb);  // (t, 1) multiplies; (t + 1, 0) / (next tile, 0, 0) is read
+      a0 = a1;
+      b0 ^= 1;
     }
-    // slot (par + nk - 1) & 1 is free for the epilogue staging; the other holds the next tile's stage 0
+    // (a0, b0) now name the next tile's stage 0; the slots of the stage just finished are free for the epilogue staging
+    unsigned char* const stgA = abase + (a0 == 0 ? 2 : a0 - 1) * W_ABYTES;
+    unsigned char* const stgB = bbase + (b0 ^ 1) * W_ABYTES;
 
     // ---- epilogue: four 64-row f32 chunks through the free stage -> whole 512-byte row segments in 16-byte lanes.
     // Image: [64 rows][64 chunks of 16 B], chunk index XORed with (row & 15): conflict-free writes (8-lane groups = 8 rows of
     // one chunk) and reads (32 lanes = the 64 chunks of one row) without padding: exactly one 64 KiB stage.
-    unsigned char* stg = smem + ((par + nk - 1) & 1) * W_BUFBYTES;
     int lane_e = lane, tid_e = tid;  // opaque copies: keeps the ~30 loop-invariant staging / output addresses out of the tile
     asm volatile("" : "+v"(lane_e), "+v"(tid_e));  // loop's live set (hoisted, they spilled 20-26 registers in the k-loop)
     const int c8e = (tid_e & 31) * 8;
@@ -167,17 +178,18 @@ __global__ __launch_bounds__(1024, 4) void gemm_bf16_w256(GemmP p) {
         for (int i = 0; i < 4; i++)
 #pragma unroll
           for (int j = 0; j < 4; j++) {
-            const int row = i * 16 + (lane_e & 15), chunk = wn * 16 + j * 4 + (lane_e >> 4);
-            *(f4v*)(stg + row * 1024 + ((chunk ^ (row & 15)) << 4)) = acc[i][j];
+            const int row = (i & 1) * 16 + (lane_e & 15), chunk = wn * 16 + j * 4 + (lane_e >> 4);
+            *(f4v*)((i < 2 ? stgA : stgB) + row * 1024 + ((chunk ^ (row & 15)) << 4)) = acc[i][j];
           }
       }
       lds_barrier();
 #pragma unroll
       for (int rr = 0; rr < 2; rr++) {
-        const int row = (tid_e >> 5) + 32 * rr;
+        const int lrow = tid_e >> 5, row = lrow + 32 * rr;
         const int ch = (tid_e & 31) * 2;
-        const f4v v0 = *(const f4v*)(stg + row * 1024 + ((ch ^ (row & 15)) << 4));
-        const f4v v1 = *(const f4v*)(stg + row * 1024 + (((ch + 1) ^ (row & 15)) << 4));
+        const unsigned char* stg = rr ? stgB : stgA;
+        const f4v v0 = *(const f4v*)(stg + lrow * 1024 + ((ch ^ (lrow & 15)) << 4));
+        const f4v v1 = *(const f4v*)(stg + lrow * 1024 + (((ch + 1) ^ (lrow & 15)) << 4));
         float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
 #pragma unroll
         for (int e = 0; e < 8; e++) v[e] = v[e] * p.alpha + bias[e];
@@ -221,24 +233,24 @@ __global__ __launch_bounds__(1024, 4) void gemm_bf16_w256(GemmP p) {
     T += G;
     tm0 = nm0;
     tn0 = nn0;
-    par = (par + nk) & 1;     // the slot the next tile's stage 0 was prefetched into
-    lds_barrier();            // every wave is done with the staging slot: it takes the new tile's stage 1
-    wstage_glds<TA>(A, p.lda, tm0, W_BK, offA, stg, tid);
-    wstage_glds<TB>(B, p.ldb, tn0, W_BK, offB, stg + W_ABYTES, tid);
+    lds_barrier();            // every wave is done with the staging slots: they take the new tile's B(1) and A(2)
+    wstage_glds<TB>(B, p.ldb, tn0, W_BK, offB, stgB, tid);
+    wstage_glds<TA>(A, p.lda, tm0, 2 * W_BK, offA, stgA, tid);
     // the new tile's first fragments (its stage 0 landed during the last stage).  They are re-read here rather than kept
     // from the last half step: 32 live fragment registers across the epilogue spilled 40 VGPRs.
-    const unsigned char* f0 = smem + par * W_BUFBYTES;
+    const unsigned char* f0 = abase + a0 * W_ABYTES;
+    const unsigned char* f1 = bbase + b0 * W_ABYTES;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       fa[i] = TA ? wfrag_kmajor(f0, wm * 64 + i * 16, 0, lane) : wfrag_rowmajor(f0, wm * 64 + i * 16, 0, lane);
-      fb[i] = TB ? wfrag_kmajor(f0 + W_ABYTES, wn * 64 + i * 16, 0, lane) : wfrag_rowmajor(f0 + W_ABYTES, wn * 64 + i * 16, 0, lane);
+      fb[i] = TB ? wfrag_kmajor(f1, wn * 64 + i * 16, 0, lane) : wfrag_rowmajor(f1, wn * 64 + i * 16, 0, lane);
     }
   }
 }
 
 // Qualifies: one problem (batch 1), no split-K, no atomics, M % 256 == N % 256 == K % 64 == 0.
 bool pero_launch_gemm_w256(const GemmP& p0, long long batch, int k_split, bool ta, bool tb, bool out_f32, hipStream_t st) {
-  if (p0.M % W_BM || p0.N % W_BN || p0.K % W_BK || p0.K < 2 * W_BK || batch != 1 || k_split > 1 || (p0.flags & PERO_GEMM_ATOMIC)) return false;
+  if (p0.M % W_BM || p0.N % W_BN || p0.K % W_BK || p0.K < 3 * W_BK || batch != 1 || k_split > 1 || (p0.flags & PERO_GEMM_ATOMIC)) return false;
   if (p0.lda >= (1LL << 22) || p0.ldb >= (1LL << 22)) return false;  // 32-bit per-lane byte offsets inside a tile
   static int num_cus = 0;
   if (!num_cus) {
