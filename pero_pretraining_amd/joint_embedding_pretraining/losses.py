@@ -2,6 +2,7 @@
 computed by HIP kernels: boolean-mask row selections become index gathers, the covariance (a D x D SYRK)
 and the per-line similarity matrices run on pero_gemm, the statistics are f32 reductions."""
 import torch
+import torch.distributed as dist
 
 from .. import ops
 from .._lib import GEMM_TILE_V, GEMM_TRANS_A, GEMM_TRANS_B
@@ -23,7 +24,8 @@ def _nz(mask, value=1):
 
 class _VICRegFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, y, im1, im2, sm1, sm2, wv, wi, wc, thr, eps, dtype):
+    def forward(ctx, x, y, im1, im2, sm1, sm2, wv, wi, wc, thr, eps, dtype, group=None):
+        # group: a torch.distributed process group -> statistics over the lines of ALL its ranks (see VICRegLoss)
         D = x.shape[-1]
         x2, y2 = _rows(x, dtype), _rows(y, dtype)
         ix, iy, jx, jy = _nz(sm1), _nz(sm2), _nz(im1), _nz(im2)
@@ -31,22 +33,40 @@ class _VICRegFn(torch.autograd.Function):
             raise RuntimeError(f"The size of tensor a ({ix.numel()}) must match the size of tensor b ({iy.numel()}) "
                                "at non-singleton dimension 0")  # what mse_loss reports in the reference
         n_inv = ix.numel()
+        n1, m_loc = jx.numel(), jx.numel() + jy.numel()
+        m, world = m_loc, 1
+        if group is not None:  # row counts of the whole batch (exact integers: int64 sum)
+            counts = torch.tensor([n_inv, m_loc], device=x2.device, dtype=torch.int64)
+            dist.all_reduce(counts, group=group)
+            n_inv, m = (int(v) for v in counts.tolist())
+            world = dist.get_world_size(group)
         inv = ops.sqdiff_rows(x2, ix, y2, iy, 1.0 / (n_inv * D))
-        n1, m = jx.numel(), jx.numel() + jy.numel()
-        m_pad = ((m + 63) // 64) * 64
+        m_pad = ((m_loc + 63) // 64) * 64
         z = torch.empty((m_pad, D), device=x2.device, dtype=dtype)
         ops.gather_rows(x2, jx, out=z[:n1])
         ops.gather_rows(y2, jy, n_rows_out=m_pad - n1, out=z[n1:])
         cs = torch.zeros(D, device=x2.device, dtype=torch.float32)
         ops.colsum(z, cs)
-        zc, sumsq = ops.center_cols(z, cs, m)
-        cvar, var = ops.vicreg_var(sumsq, m, thr, eps)
+        if group is not None:
+            # exchange 1: column sums (D floats) -> the GLOBAL mean; pero_center_cols divides by its row count, so the
+            # global sums are rescaled by m_loc / m.  The invariance partial sum rides along.
+            pack = torch.cat([cs, inv])
+            dist.all_reduce(pack, group=group)
+            cs, inv = pack[:D] * (m_loc / m), pack[D:].clone()
+        zc, sumsq = ops.center_cols(z, cs.contiguous(), m_loc)
+        # rows centred with the global mean: sum over ranks of zc^T zc IS the global scatter matrix
         cov = ops.gemm(zc, zc, trans_a=True, trans_b=True, alpha=1.0 / (m - 1), out_dtype=torch.float32,
                        extra_flags=GEMM_TILE_V)  # the loss products run alone on the GPU: 256x256x64 tiles
+        if group is not None:
+            # exchange 2: the D x D scatter matrix (f32: 64 MiB at D = 4096) and the D squared column norms
+            dist.all_reduce(cov, group=group)
+            dist.all_reduce(sumsq, group=group)
+        cvar, var = ops.vicreg_var(sumsq, m, thr, eps)
         G, covl = ops.vicreg_cov(cov, cvar, m, wv, wc, dtype)
         loss = wv * var + wi * inv + wc * covl
         ctx.save_for_backward(x2, y2, ix, iy, jx, jy, zc, G)
-        ctx.meta = (x.shape, y.shape, n1, m, wi * 2.0 / (n_inv * D), dtype)
+        ctx.meta = (x.shape, y.shape, n1, m_loc, wi * 2.0 / (n_inv * D), dtype)
+        ctx.seed = float(world)
         ctx.mark_non_differentiable(var, inv, covl)
         return loss[0], var[0], inv[0], covl[0]
 
@@ -54,21 +74,32 @@ class _VICRegFn(torch.autograd.Function):
     def backward(ctx, g, _gv, _gi, _gc):
         x2, y2, ix, iy, jx, jy, zc, G = ctx.saved_tensors
         xs, ys, n1, m, inv_coef, dtype = ctx.meta
-        gdev = g.detach().reshape(1).to(torch.float32)
+        # global statistics: every rank holds the SAME loss and differentiates it w.r.t. its own rows; the data-parallel
+        # gradient AVERAGE over ranks would divide the sum of those parts by world, so the seed is multiplied by world
+        gdev = g.detach().reshape(1).to(torch.float32) * ctx.seed
         dzc = ops.gemm(zc, G, extra_flags=GEMM_TILE_V)  # (m_pad, D): d(wv*var + wc*cov)/d zc
         dx = torch.zeros_like(x2)
         dy = torch.zeros_like(y2)
         ops.scatter_add_rows_scaled(dzc[:n1], jx, dx, gdev)
         ops.scatter_add_rows_scaled(dzc[n1:m], jy, dy, gdev)
         ops.sqdiff_rows_bwd(x2, ix, y2, iy, dx, dy, gdev, inv_coef)
-        return (dx.view(xs), dy.view(ys)) + (None,) * 10
+        return (dx.view(xs), dy.view(ys)) + (None,) * 11
 
 
 class VICRegLoss(torch.nn.Module):
-    """joint_embedding_pretraining/losses.py:3-47."""
+    """joint_embedding_pretraining/losses.py:3-47.
 
-    def __init__(self, variance_weight=1.0, invariance_weight=1.0, covariance_weight=1.0, variance_threshold=1.0):
+    global_statistics=True (no reference counterpart on one device): mean, variance, covariance
+    and the invariance mean are taken over the lines of ALL ranks of `process_group` - two exchanges per step (D + 1
+    floats; D x D + D floats).  Every rank then returns the loss the reference computes on the concatenated batch, and
+    the backward is seeded with world_size, so that data-parallel gradient averaging yields exactly the single-process
+    gradient of that batch.  Default False: per-rank statistics, i.e. the reference's loss on each rank's shard."""
+
+    def __init__(self, variance_weight=1.0, invariance_weight=1.0, covariance_weight=1.0, variance_threshold=1.0,
+                 global_statistics=False, process_group=None):
         super().__init__()
+        self.global_statistics = global_statistics
+        self.process_group = process_group
         self.variance_weight = variance_weight
         self.invariance_weight = invariance_weight
         self.covariance_weight = covariance_weight
@@ -82,8 +113,16 @@ class VICRegLoss(torch.nn.Module):
         masks = [torch.as_tensor(m).to(dev) for m in (image_masks1, image_masks2, shift_masks1, shift_masks2)]
         loss, var, inv, cov = _VICRegFn.apply(x, y, *masks, float(self.variance_weight), float(self.invariance_weight),
                                               float(self.covariance_weight), float(self.variance_threshold), self.eps,
-                                              compute_dtype())
+                                              compute_dtype(), self._group())
         return {"loss": loss, "loss.variance": var, "loss.invariance": inv, "loss.covariance": cov}
+
+
+    def _group(self):
+        if not self.global_statistics:
+            return None
+        if not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError("VICRegLoss(global_statistics=True) needs an initialised torch.distributed process group")
+        return self.process_group if self.process_group is not None else dist.group.WORLD
 
 
 class _NTXentFn(torch.autograd.Function):

@@ -14,12 +14,13 @@ from .tester import Tester
 from .trainer import Trainer
 
 
-def init_model(device, backbone_definition, head_definition, loss_type="vicreg", path=None):
+def init_model(device, backbone_definition, head_definition, loss_type="vicreg", path=None, global_statistics=False):
     """train.py:54-72."""
     backbone = init_backbone(backbone_definition)
     head = init_head(head_definition)
     if loss_type == "vicreg":
-        loss = VICRegLoss()
+        # global_statistics: VICReg mean / variance / covariance over the lines of all data-parallel ranks (losses.py)
+        loss = VICRegLoss(global_statistics=global_statistics)
     elif loss_type == "ntxent":
         loss = NTXentLoss()
     else:

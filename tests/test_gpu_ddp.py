@@ -125,3 +125,71 @@ def test_two_rank_global_mean_equals_single_process_on_the_whole_batch():
     for k, p in model.named_parameters():
         want = p.grad.cpu().numpy()
         assert np.abs(grads[k] - want).max() <= 1e-5 * max(np.abs(want).max(), 1e-3), k
+
+
+# ---- exact-global VICReg statistics -------------------------------------------------------
+def _vicreg_data(rank):
+    """Ragged shard: rank 0 holds 3 lines, rank 1 holds 2; three-valued shift masks, image masks with padding."""
+    rng = np.random.default_rng(7 + rank)
+    n, s, d = (3, 2)[rank], 24, 256
+    x = rng.standard_normal((n, s, d)).astype(np.float32)
+    y = (x + 0.3 * rng.standard_normal((n, s, d))).astype(np.float32)
+    im1 = np.ones((n, s), np.uint8); im2 = np.ones((n, s), np.uint8)
+    sm1 = np.zeros((n, s), np.uint8); sm2 = np.zeros((n, s), np.uint8)
+    for i in range(n):
+        width = int(rng.integers(12, s + 1))
+        im1[i, width:] = 0
+        im2[i, width:] = 0
+        shift = int(rng.integers(0, 5))
+        sm1[i, shift:width] = 1
+        sm2[i, :width - shift] = 1
+        sm1[i, width:] = 2  # shared padding positions (dataloader.py:137-138): selected by neither loss term
+        sm2[i, width:] = 2
+    return x, y, im1, im2, sm1, sm2
+
+
+def _vicreg_worker(rank, world, port, out_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pero_pretraining_amd.joint_embedding_pretraining.losses import VICRegLoss
+    x, y, *masks = _vicreg_data(rank)
+    xg = torch.from_numpy(x).cuda().requires_grad_(True)
+    yg = torch.from_numpy(y).cuda().requires_grad_(True)
+    res = VICRegLoss(variance_weight=2.0, invariance_weight=3.0, covariance_weight=0.5, global_statistics=True)(
+        xg, yg, *[torch.from_numpy(m).cuda() for m in masks])
+    res["loss"].backward()
+    torch.cuda.synchronize()
+    out_q.put((rank, {k: float(v) for k, v in res.items()}, xg.grad.cpu().numpy(), yg.grad.cpu().numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_global_vicreg_statistics_equal_the_loss_on_the_concatenated_batch():
+    from oracle import pero_oracle as O
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_vicreg_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict((r, rest) for r, *rest in (q.get(timeout=240) for _ in range(2)))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    parts = [_vicreg_data(r) for r in range(2)]
+    x, y, *masks = (np.concatenate([p[i] for p in parts]) for i in range(6))
+    xo = torch.from_numpy(x).requires_grad_(True)
+    yo = torch.from_numpy(y).requires_grad_(True)
+    ref = O.vicreg_loss(xo, yo, *masks, variance_weight=2.0, invariance_weight=3.0, covariance_weight=0.5)
+    ref["loss"].backward()
+    n0 = parts[0][0].shape[0]
+    for r in range(2):
+        vals, dx, dy = got[r]
+        for k in ref:  # every rank reports the loss of the WHOLE batch
+            assert abs(vals[k] - float(ref[k])) <= 1e-4 * abs(float(ref[k])) + 1e-7, (r, k, vals[k], float(ref[k]))
+        rows = slice(0, n0) if r == 0 else slice(n0, None)
+        for have, want in ((dx, xo.grad[rows].numpy()), (dy, yo.grad[rows].numpy())):
+            # seeded with world_size: the data-parallel average (divide by 2) gives the single-process gradient
+            assert np.abs(have / 2 - want).max() <= 1e-4 * np.abs(want).max()
