@@ -1,6 +1,7 @@
 """Masked pre-training model with the API of the reference's masked_pretraining/model.py
 (init_backbone, init_head, MaskedTransformerEncoder, MaskedCrossEntropyLoss, LinearHead), computing
 through the HIP kernels."""
+import numpy as np
 import torch
 
 from .. import functional as F
@@ -91,6 +92,24 @@ class _MaskedCEFn(torch.autograd.Function):
         return ops.masked_ce_bwd(lg, lab, msk, work, ctx.uw, dloss=dl).view(ctx.shape), None, None, None
 
 
+class _GatherTokensFn(torch.autograd.Function):
+    """rows[i] = tokens[index[i]] for i < index.numel(), zero rows up to n_out; the backward scatters the row gradients
+    into a zero matrix (the index entries are distinct positions)."""
+
+    @staticmethod
+    def forward(ctx, tokens, index, n_out):
+        ctx.save_for_backward(index)
+        ctx.shape = tokens.shape
+        return ops.gather_rows(tokens.detach(), index, n_rows_out=n_out)
+
+    @staticmethod
+    def backward(ctx, drows):
+        (index,) = ctx.saved_tensors
+        dx = torch.zeros(ctx.shape, device=drows.device, dtype=drows.dtype)
+        ops.scatter_add_rows(drows.contiguous(), index, dx)
+        return dx, None, None
+
+
 class MaskedCrossEntropyLoss(torch.nn.Module):
     """masked_pretraining/model.py:72-95."""
 
@@ -107,13 +126,48 @@ class MaskedCrossEntropyLoss(torch.nn.Module):
 class MaskedTransformerEncoder(torch.nn.Module):
     """masked_pretraining/model.py:33-69."""
 
+    # "all": the head is evaluated on every position, as the reference does (model.py:41-63).
+    # "masked": in TRAINING steps whose loss reads the masked positions only (unmasked_weight None) the head, the loss and
+    # their backward run on those rows alone (about 15 % of them: SURVEY.md section 8 a8/a9) - same loss and gradients,
+    # result["output"] is None and result["output_rows"] / result["rows"] hold the logits of the masked positions.
+    head_rows = "all"
+
     def __init__(self, backbone, head, loss=None):
         super().__init__()
         self.backbone = backbone
         self.head = head
         self.loss = MaskedCrossEntropyLoss() if loss is None else loss
 
-    def forward(self, x, labels=None, mask=None):
+    def _forward_masked_rows(self, x, labels, mask, rows=None):
+        if rows is not None:  # flat positions with mask == 1, listed by the caller (int64): no host sync for the count
+            index = rows.reshape(-1)
+        elif isinstance(mask, torch.Tensor):
+            index = torch.nonzero(mask.reshape(-1) == 1, as_tuple=False).reshape(-1)  # one host sync (row count)
+        else:  # the reference's BatchOperator hands the mask over as a host array: the count costs nothing
+            index = torch.from_numpy(np.flatnonzero(np.asarray(mask).reshape(-1) == 1))
+        n = index.numel()
+        if n == 0:
+            return None  # the dense path reproduces the reference's NaN for an empty selection
+        tokens = self.backbone.encode_tokens(x, mask)                # (N*S, d)
+        index = index.to(tokens.device)
+        n_pad = ((n + 255) // 256) * 256                              # whole 256-row GEMM tiles; pad rows are zero
+        rows = _GatherTokensFn.apply(tokens, index, n_pad)
+        logits = self.head(rows)                                      # (n_pad, V)
+        row_labels = torch.zeros(n_pad, device=tokens.device, dtype=torch.int64)
+        row_labels[:n] = torch.as_tensor(labels).to(tokens.device).reshape(-1)[index]
+        row_mask = torch.zeros(n_pad, device=tokens.device, dtype=torch.int64)
+        row_mask[:n] = 1
+        loss = self.loss(logits.view(1, n_pad, -1), row_labels.view(1, n_pad), row_mask.view(1, n_pad))
+        return {"output": None, "loss": loss, "output_rows": logits[:n], "rows": index}
+
+    def forward(self, x, labels=None, mask=None, rows=None):
+        if self.head_rows == "masked" and self.training and labels is not None and mask is not None \
+                and getattr(self.loss, "unmasked_weight", None) is None:
+            result = self._forward_masked_rows(x, labels, mask, rows)
+            if result is not None:
+                return result
+        elif self.head_rows not in ("all", "masked"):
+            raise ValueError(f"Unknown head_rows: {self.head_rows}")
         output = self.encode(x, mask)
         if mask is not None and not isinstance(mask, torch.Tensor):
             mask = torch.from_numpy(mask).to(output.device)

@@ -72,10 +72,10 @@ class Trainer:
         images, labels, mask = self.batch_operator.prepare_batch(batch)
         return self.train_step_prepared(images, labels, mask)
 
-    def _forward_backward(self, images, labels, mask):
+    def _forward_backward(self, images, labels, mask, rows=None):
         self.optimizer.zero_grad()
         with autocast(self.bfloat16):
-            output = self.model.forward(images, labels, mask)
+            output = self.model.forward(images, labels, mask) if rows is None else self.model.forward(images, labels, mask, rows=rows)
         loss = output["loss"]
         seed = None
         if self.data_parallel is not None:
@@ -90,8 +90,9 @@ class Trainer:
             self.data_parallel.finish_backward()
         return loss.detach()
 
-    def train_step_prepared(self, images, labels, mask):
-        if self.hip_graph and self.data_parallel is None:
+    def train_step_prepared(self, images, labels, mask, rows=None):
+        """rows (optional, model.head_rows == "masked"): int64 device tensor of the flat positions with mask == 1."""
+        if self.hip_graph and self.data_parallel is None and rows is None:
             tensors = [images, torch.as_tensor(labels).to(images.device), torch.as_tensor(mask).to(images.device)]
             key = tuple((tuple(t.shape), t.dtype) for t in tensors) + (self.model.training,)
             g = self._graphs.get(key)
@@ -99,7 +100,7 @@ class Trainer:
                 g = self._graphs[key] = _StepGraph(self, tensors)
             loss = g.replay(tensors)
         else:
-            loss = self._forward_backward(images, labels, mask)
+            loss = self._forward_backward(images, labels, mask, rows)
         self.optimizer.step()
         return loss
 
