@@ -145,6 +145,10 @@ int pero_colsum(const void* x, float* out, int64_t rows, int64_t cols, int64_t l
 /* out[m][b] = sum over columns 128b..128b+127 of x[m][c] * y[m][c]  (bf16 x, y; the pass PERO_GEMM_ROWDOT fuses) */
 int pero_rowdot_blocks(const void* x, const void* y, float* out, int64_t rows, int64_t cols, int64_t ldx, int64_t ldy,
                        void* stream);
+/* Transposed bf16 copies of every matrix of a flat buffer in one launch (2-byte elements): table (device, int64[n][5]) =
+ * {src offset, dst offset, rows, cols, first tile} in elements / 64x64 tiles; dst matrix t is [cols][rows].  The input
+ * gradient dX = dY W (torch.nn.Linear backward, models/transformers.py:36-43 layers) reads these K-contiguous copies. */
+int pero_transpose_multi(const void* src, void* dst, const int64_t* table, int64_t n_matrices, int64_t total_tiles, void* stream);
 /* f32 -> bf16 copy (low-precision weight copies) */
 int pero_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream);
 int pero_cast_bf16_f32(const void* src, float* dst, int64_t n, void* stream);

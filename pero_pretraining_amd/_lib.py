@@ -38,6 +38,7 @@ SIGNATURES = {
     "pero_masked_ce_bwd": [_vp, _vp, _vp, _f32, _vp, _vp, _vp, _i64, _i64, _i32, _vp],
     "pero_colsum": [_vp, _vp, _i64, _i64, _i64, _i32, _vp],
     "pero_cast_f32_bf16": [_vp, _vp, _i64, _vp],
+    "pero_transpose_multi": [_vp, _vp, _vp, _i64, _i64, _vp],
     "pero_cast_bf16_f32": [_vp, _vp, _i64, _vp],
     "pero_scale": [_vp, _i64, _f32, _i32, _vp],
     "pero_adam_step": [_vp, _vp, _vp, _vp, _vp, _i64, _f64, _f64, _f64, _f64, _i64, _f64, _vp],

@@ -344,3 +344,63 @@ extern "C" int pero_rowdot_blocks(const void* x, const void* y, float* out, int6
   PERO_CHECK_LAUNCH("pero_rowdot_blocks");
   return PERO_OK;
 }
+
+// --------------------------------------------------------------------------------------------
+// Transposed bf16 weight copies, every matrix of a flat buffer in ONE launch.  The input gradient dX = dY W reads W
+// K-contiguous from such a copy ([in][out]) instead of k-major from W itself - the 256x256x64 tile kernels run 10-20 %
+// faster on K-contiguous operands.  table[t] = {src offset, dst offset, rows, cols, first tile}
+// (elements / tiles of 64 x 64); a workgroup finds its matrix by scanning the <= a-few-dozen entries.
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_multi_k(const bf16raw* src, bf16raw* dst, const long long* table, int n) {
+  __shared__ bf16raw tile[64][66];  // pitch 33 dwords: a column walk touches 32 different banks
+  const long long bid = blockIdx.x;
+  int t = 0;
+  while (t + 1 < n && table[(t + 1) * 5 + 4] <= bid) t++;
+  const long long so = table[t * 5], dof = table[t * 5 + 1], rows = table[t * 5 + 2], cols = table[t * 5 + 3];
+  const long long local = bid - table[t * 5 + 4];
+  const long long tiles_c = (cols + 63) / 64;
+  const long long r0 = (local / tiles_c) * 64, c0 = (local % tiles_c) * 64;
+  const bf16raw* s = src + so;
+  bf16raw* d = dst + dof;
+  const int tid = threadIdx.x, c8 = (tid & 7) * 8;
+  const bool vec = (rows % 8 == 0) && (cols % 8 == 0) && (so % 8 == 0) && (dof % 8 == 0);
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    const int r = (tid >> 3) + 32 * h;
+    if (r0 + r < rows) {
+      if (vec && c0 + c8 + 8 <= cols) {
+        const uint4 v = *(const uint4*)(s + (r0 + r) * cols + c0 + c8);
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; e++) { tile[r][c8 + 2 * e] = (bf16raw)(w[e] & 0xffffu); tile[r][c8 + 2 * e + 1] = (bf16raw)(w[e] >> 16); }
+      } else {
+        for (int e = 0; e < 8; e++)
+          if (c0 + c8 + e < cols) tile[r][c8 + e] = s[(r0 + r) * cols + c0 + c8 + e];
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    const int c = (tid >> 3) + 32 * h;  // output row = source column
+    if (c0 + c < cols) {
+      if (vec && r0 + c8 + 8 <= rows) {
+        unsigned w[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) w[e] = (unsigned)tile[c8 + 2 * e][c] | ((unsigned)tile[c8 + 2 * e + 1][c] << 16);
+        *(uint4*)(d + (c0 + c) * rows + r0 + c8) = make_uint4(w[0], w[1], w[2], w[3]);
+      } else {
+        for (int e = 0; e < 8; e++)
+          if (r0 + c8 + e < rows) d[(c0 + c) * rows + r0 + c8 + e] = tile[c8 + e][c];
+      }
+    }
+  }
+}
+extern "C" int pero_transpose_multi(const void* src, void* dst, const int64_t* table, int64_t n_matrices, int64_t total_tiles, void* stream) {
+  PERO_REQUIRE(src && dst && table && n_matrices > 0 && total_tiles > 0 && total_tiles < (1LL << 31), "pero_transpose_multi: bad arguments");
+  PERO_REQUIRE(aligned16(src) && aligned16(dst), "pero_transpose_multi: 16-byte alignment");
+  hipLaunchKernelGGL(transpose_multi_k, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream, (const bf16raw*)src, (bf16raw*)dst,
+                     (const long long*)table, (int)n_matrices);
+  PERO_CHECK_LAUNCH("pero_transpose_multi");
+  return PERO_OK;
+}

@@ -33,7 +33,9 @@ def ensure_grad(p):
     return p.grad
 
 
-FWD_TILE_FLAGS = GEMM_TILE_V  # forward products run alone on the GPU (no side-stream kernels beside them): 256x256x64 tiles
+FWD_TILE_FLAGS = GEMM_TILE_V
+DX_ON_WT = True          # input gradients on transposed weight copies (lowp.weight_t)
+DX_TILE_FLAGS = GEMM_TILE_V  # forward products run alone on the GPU (no side-stream kernels beside them): 256x256x64 tiles
 
 
 def linear_fwd(x, w, b, dtype, residual=None, relu=False, out_dtype=None):
@@ -125,6 +127,10 @@ def linear_bwd(dy, x, w, b, dtype, need_dx=True, gate=None, residual=None, bias_
         grads()
     if not need_dx:
         return None
+    if DX_ON_WT and dtype == torch.bfloat16:
+        # dX = dY (W^T)^T on a transposed bf16 weight copy: both operands K-contiguous, 256x256x64 tiles
+        return ops.gemm(dy, lowp.weight_t(w), residual=residual, gate=gate, colsum_into=dx_colsum_into, rowdot=dx_rowdot,
+                        extra_flags=DX_TILE_FLAGS)
     return ops.gemm(dy, lowp.weight(w, dtype).view(w.shape[0], -1), trans_b=True, residual=residual, gate=gate,
                     colsum_into=dx_colsum_into, rowdot=dx_rowdot)
 

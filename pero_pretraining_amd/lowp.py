@@ -63,3 +63,43 @@ def put(p, lp_view):
 def weight(p, dtype):
     """Parameter tensor in the requested compute dtype."""
     return p.detach() if dtype == torch.float32 else get(p)
+
+
+_cache_t = {}  # id(p) -> [key, transposed bf16 copy (in, out), device table, tiles, weakref]
+
+
+def _ref_t(p):
+    key = id(p)
+    return weakref.ref(p, lambda _r: _cache_t.pop(key, None))
+
+
+def put_t(p, lp_t_view):
+    """Register `lp_t_view` (bf16 (in, out), already holding the transposed current value of p's 2-D view) - the fused
+    optimizer refreshes all of them with one pero_transpose_multi launch per step."""
+    _cache_t[id(p)] = [_key(p), lp_t_view, None, 0, _ref_t(p)]
+
+
+def weight_t(p):
+    """bf16 copy of the 2-D view (out, in) of weight p, TRANSPOSED to (in, out): the input gradient dX = dY W then runs as a
+    K-contiguous ("NT") product, 10-20 % faster on the 256x256x64 tile kernels than reading W k-major.
+    Cached per parameter version; parameters owned by FusedAdam are refreshed by the optimizer step itself."""
+    ent = _cache_t.get(id(p))
+    if ent is not None and ent[4]() is not p:
+        del _cache_t[id(p)]
+        ent = None
+    k = _key(p)
+    if ent is not None and ent[0] == k:
+        return ent[1]
+    src = get(p)  # current bf16 copy (re-cast if p changed)
+    rows = p.shape[0]
+    cols = p.numel() // rows
+    if ent is None:
+        ent = _cache_t[id(p)] = [k, torch.empty((cols, rows), device=p.device, dtype=torch.bfloat16), None, 0, _ref_t(p)]
+    if src.data_ptr() % 16 or ent[1].data_ptr() % 16:  # unaligned view: plumbing fallback
+        ent[1].copy_(src.view(rows, cols).t())
+    else:
+        if ent[2] is None:
+            ent[2], ent[3] = ops.transpose_table([(0, 0, rows, cols)], p.device)
+        ops.transpose_multi(src, ent[1], ent[2], ent[3])
+    ent[0] = k
+    return ent[1]

@@ -171,6 +171,22 @@ def colsum(x, out):
     return out
 
 
+def transpose_table(entries, device):
+    """entries: [(src offset, dst offset, rows, cols)] -> (device table for transpose_multi, total 64x64 tiles)."""
+    rows_, tiles = [], 0
+    for so, do, r, c in entries:
+        rows_.append([so, do, r, c, tiles])
+        tiles += ((r + 63) // 64) * ((c + 63) // 64)
+    return torch.tensor(rows_, dtype=torch.int64).to(device), tiles
+
+
+def transpose_multi(src, dst, table, tiles):
+    """dst matrix t = src matrix t transposed, for every row of `table` (2-byte elements, one launch)."""
+    assert src.element_size() == 2 and dst.element_size() == 2 and table.dtype == torch.int64 and table.is_cuda
+    call("pero_transpose_multi", ptr(src), ptr(dst), ptr(table), table.shape[0], tiles, stream())
+    return dst
+
+
 def cast_to_bf16(src, dst):
     call("pero_cast_f32_bf16", ptr(src), ptr(dst), src.numel(), stream())
     return dst

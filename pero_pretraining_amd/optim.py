@@ -49,14 +49,30 @@ class FusedAdam(torch.optim.Optimizer):
             ops.cast_to_bf16(fp, flp)
             for p, o in zip(ps, offs):
                 lowp.put(p, flp[o:o + p.numel()].view(p.shape))
+            # transposed bf16 copies of the matrices (lowp.weight_t: the input-gradient products read them), same offsets
+            mats = [(o, o, p.shape[0], p.numel() // p.shape[0]) for p, o in zip(ps, offs) if p.dim() >= 2]
+            flpt, ttable, ttiles = None, None, 0
+            if mats:
+                flpt = torch.zeros(total, device=dev, dtype=torch.bfloat16)
+                ttable, ttiles = ops.transpose_table(mats, dev)
+                ops.transpose_multi(flp, flpt, ttable, ttiles)
+                for p, o in zip(ps, offs):
+                    if p.dim() >= 2:
+                        lowp.put_t(p, flpt[o:o + p.numel()].view(p.numel() // p.shape[0], p.shape[0]))
             self._flat.append(dict(p=fp, g=fg, m=torch.zeros_like(fp), v=torch.zeros_like(fp), lp=flp, step=0,
-                                   params=ps, offsets=offs))
+                                   params=ps, offsets=offs, lpt=flpt, ttable=ttable, ttiles=ttiles))
 
     def refresh_lowp(self):
         """Re-cast the bf16 copies after the flat parameters were written from outside (broadcast, load)."""
         for f in self._flat:
             if f is not None:
                 ops.cast_to_bf16(f["p"], f["lp"])
+                self._transpose(f)
+
+    @staticmethod
+    def _transpose(f):
+        if f["lpt"] is not None:
+            ops.transpose_multi(f["lp"], f["lpt"], f["ttable"], f["ttiles"])
 
     # flat views for data-parallel gradient reduction
     def flat_grads(self):
@@ -140,4 +156,5 @@ class FusedAdam(torch.optim.Optimizer):
             b1, b2 = group["betas"]
             ops.adam_step(f["p"], f["g"], f["m"], f["v"], f["lp"], group["lr"], b1, b2, group["eps"], f["step"],
                           self.grad_scale)
+            self._transpose(f)
         return loss

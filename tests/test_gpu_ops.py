@@ -512,3 +512,26 @@ def test_gemm_fused_row_dots(M, N, K):
     assert torch.equal(out, ref)
     want = (ref.float() * y.float()).view(M, N // 128, 128).sum(-1)
     assert float((dots - want).abs().max()) <= 1e-3 * max(1.0, float(want.abs().max()))
+
+
+def test_transpose_multi_and_transposed_weight_copies():
+    """pero_transpose_multi: every matrix of a flat bf16 buffer transposed in one launch (aligned 16-byte path, ragged
+    scalar path, sizes that are not multiples of the 64 x 64 tile); lowp.weight_t follows parameter updates."""
+    from pero_pretraining_amd import lowp, ops
+    shapes = [(1536, 512), (64, 64), (100, 36), (8, 1000), (3, 5), (520, 72)]
+    offs, total = [], 0
+    for r, c in shapes:
+        offs.append(total)
+        total += ((r * c + 7) // 8) * 8
+    flat = torch.randn(total, device="cuda").to(torch.bfloat16)
+    out = torch.zeros_like(flat)
+    table, tiles = ops.transpose_table([(o, o, r, c) for o, (r, c) in zip(offs, shapes)], flat.device)
+    ops.transpose_multi(flat, out, table, tiles)
+    for o, (r, c) in zip(offs, shapes):
+        assert torch.equal(out[o:o + r * c].view(c, r), flat[o:o + r * c].view(r, c).t()), (r, c)
+    p = torch.nn.Parameter(torch.randn(256, 3, 8, 8, device="cuda"))
+    wt = lowp.weight_t(p)
+    assert wt.shape == (192, 256) and torch.equal(wt, p.detach().to(torch.bfloat16).view(256, 192).t())
+    with torch.no_grad():
+        p.mul_(2.0)
+    assert torch.equal(lowp.weight_t(p), p.detach().to(torch.bfloat16).view(256, 192).t())

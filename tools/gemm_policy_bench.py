@@ -20,7 +20,9 @@ for (N, K, tag) in [(1536, 512, "qkv"), (512, 512, "out"), (2048, 512, "ffn1"), 
     dy = (torch.randn(M, N, device="cuda") * 0.5).bfloat16()
     y = torch.empty(M, N, device="cuda", dtype=torch.bfloat16); dx = torch.empty(M, K, device="cuda", dtype=torch.bfloat16)
     fl = 2.0 * M * N * K
-    for name, fn in [("NT", lambda: ops.gemm(x, w, out=y)), ("NN", lambda: ops.gemm(dy, w, out=dx, trans_b=True))]:
+    wt = w.t().contiguous()  # [K, N]: dX = dY W as an NT product on a transposed weight copy
+    for name, fn in [("NT", lambda: ops.gemm(x, w, out=y)), ("NN", lambda: ops.gemm(dy, w, out=dx, trans_b=True)),
+                     ("dX on W^T (NT)", lambda: ops.gemm(dy, wt, out=dx))]:
         res = {}
         for rep in range(2):
             for p in pols:
