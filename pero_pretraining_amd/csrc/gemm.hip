@@ -521,7 +521,13 @@ static int gemm_dispatch(const void* A, const void* B, void* C, const float* bia
       PERO_CHECK_LAUNCH("pero_gemm(x256)");
       return PERO_OK;
     }
-    if ((g_gemm_policy == 12 || (g_gemm_policy == 0 && g_gemm_persistent && (flags & PERO_GEMM_TILE_V) && t256 >= 192 && !want_cs)) && !forced0 && !atomic && pero_launch_gemm_w256(p, batch, k_split, ta, tb, out_dtype == PERO_F32, st)) {
+    // w256 carries the fused row-dot epilogue (K-contiguous bf16 products only).  Its column-sum epilogue (EPI 1) is NOT
+    // used: the per-tile atomics sit in the in-order memory queue ahead of the next tile's first stage and the persistent
+    // loop waits for them - linear2's input gradient took 325 us against 232 us with gemm_bf16_v256, whose atomics are the
+    // last thing a workgroup does (tools/dx_epi_bench.py).
+    const bool w_fuse = want_rd && !ta && !tb && out_dtype != PERO_F32;
+    if ((g_gemm_policy == 12 || (g_gemm_policy == 0 && g_gemm_persistent && (flags & PERO_GEMM_TILE_V) && t256 >= 192 && (!want_cs || w_fuse))) && !forced0 && !atomic && pero_launch_gemm_w256(w_fuse ? pc : p, batch, k_split, ta, tb, out_dtype == PERO_F32, st)) {
+      *colsum_fused = w_fuse;
       PERO_CHECK_LAUNCH("pero_gemm(w256)");
       return PERO_OK;
     }

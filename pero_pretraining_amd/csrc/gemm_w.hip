@@ -60,7 +60,11 @@ __device__ __forceinline__ void wstage_glds(const bf16raw* X, long long ld, long
                                    (__attribute__((address_space(3))) void*)(dst + 16384), 16, 0, 0);
 }
 
-template <bool TA, bool TB, bool OUTF32>
+// EPI: 0 = bias / residual / ReLU / ReLU-gate epilogue; 1 = + column sums of the stored result accumulated into p.bias (an
+// OUTPUT then: PERO_GEMM_COLSUM); 2 = per-128-column row dots of the stored result with p.gate written to p.bias
+// ([M][N / 128] f32: PERO_GEMM_ROWDOT).  Modes 1 and 2 exist for the K-contiguous bf16 products only (the input-gradient
+// products on transposed weight copies).
+template <bool TA, bool TB, bool OUTF32, int EPI>
 __global__ __launch_bounds__(1024, 4) void gemm_bf16_w256(GemmP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -169,7 +173,8 @@ __global__ __launch_bounds__(1024, 4) void gemm_bf16_w256(GemmP p) {
     const int c8e = (tid_e & 31) * 8;
     float bias[8];
 #pragma unroll
-    for (int e = 0; e < 8; e++) bias[e] = p.bias ? p.bias[tn0 + c8e + e] : 0.f;
+    for (int e = 0; e < 8; e++) bias[e] = (EPI == 0 && p.bias) ? p.bias[tn0 + c8e + e] : 0.f;
+    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int qq = 0; qq < 4; qq++) {
       if (qq > 0) lds_barrier();  // previous chunk's staging reads are done (chunk 0: the stage was released by the last mid-barrier)
@@ -204,7 +209,20 @@ __global__ __launch_bounds__(1024, 4) void gemm_bf16_w256(GemmP p) {
 #pragma unroll
           for (int e = 0; e < 8; e++) v[e] = fmaxf(v[e], 0.f);
         }
-        if (p.gate) {
+        if (EPI == 2) {
+          // this thread's 8 columns of row `grow` (rounded to bf16 as they are stored) times the same columns of p.gate; the
+          // 16 lanes of a 128-column block share the row and meet by shuffles
+          const uint4 gg = *(const uint4*)((const bf16raw*)p.gate + grow * p.ldg + tn0 + c8e);
+          const unsigned w[4] = {gg.x, gg.y, gg.z, gg.w};
+          float dot = 0.f;
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            dot += bf2f(f2bf(v[2 * e])) * __uint_as_float(w[e] << 16);
+            dot += bf2f(f2bf(v[2 * e + 1])) * __uint_as_float(w[e] & 0xffff0000u);
+          }
+          dot += __shfl_xor(dot, 1, 64); dot += __shfl_xor(dot, 2, 64); dot += __shfl_xor(dot, 4, 64); dot += __shfl_xor(dot, 8, 64);
+          if ((tid_e & 15) == 0) ((float*)p.bias)[grow * (p.N >> 7) + (tn0 >> 7) + ((tid_e >> 4) & 1)] = dot;
+        } else if (p.gate) {
           const uint4 gg = *(const uint4*)((const bf16raw*)p.gate + grow * p.ldg + tn0 + c8e);
           const unsigned w[4] = {gg.x, gg.y, gg.z, gg.w};
 #pragma unroll
@@ -212,6 +230,10 @@ __global__ __launch_bounds__(1024, 4) void gemm_bf16_w256(GemmP p) {
             if (!(__uint_as_float(w[e] << 16) > 0.f)) v[2 * e] = 0.f;
             if (!(__uint_as_float(w[e] & 0xffff0000u) > 0.f)) v[2 * e + 1] = 0.f;
           }
+        }
+        if (EPI == 1) {
+#pragma unroll
+          for (int e = 0; e < 8; e++) cs[e] += v[e];
         }
         if (OUTF32) {
           float* C = (float*)p.C + grow * p.ldc + tn0 + c8e;
@@ -227,6 +249,25 @@ __global__ __launch_bounds__(1024, 4) void gemm_bf16_w256(GemmP p) {
           o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]); o.z = pack2bf(v[4], v[5]); o.w = pack2bf(v[6], v[7]);
           *(uint4*)((bf16raw*)p.C + grow * p.ldc + tn0 + c8e) = o;
         }
+      }
+    }
+    if (EPI == 1) {
+      // tile column sums: registers (8 rows per thread) -> lane ^ 32 (the wave's other row) -> LDS over the 16 waves -> one
+      // atomic per column and tile.  The scratch is the A staging slot (free: the chunk loop's reads are behind the barrier).
+#pragma unroll
+      for (int e = 0; e < 8; e++) cs[e] += __shfl_xor(cs[e], 32, 64);
+      lds_barrier();
+      float* red = (float*)stgA;
+      if ((tid_e & 63) < 32) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) red[(tid_e >> 6) * 256 + (tid_e & 31) * 8 + e] = cs[e];
+      }
+      lds_barrier();
+      if (tid_e < 256) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; w++) t += red[w * 256 + tid_e];
+        atomicAdd((float*)p.bias + tn0 + tid_e, t);
       }
     }
     if (!has_next) break;
@@ -264,19 +305,27 @@ bool pero_launch_gemm_w256(const GemmP& p0, long long batch, int k_split, bool t
   const long long nt = (p.M / W_BM) * (p.N / W_BN);
   const unsigned G = (unsigned)(nt < num_cus ? ((nt + 7) / 8) * 8 : num_cus);
   dim3 grid(G), block(1024);
-#define LAUNCH_W(TA_, TB_, OF_)                                                                                            \
+#define LAUNCH_W(TA_, TB_, OF_, EP_)                                                                                            \
   do {                                                                                                                     \
     static bool attr_set = false;                                                                                          \
     if (!attr_set) {                                                                                                       \
-      hipFuncSetAttribute((const void*)gemm_bf16_w256<TA_, TB_, OF_>, hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS_BYTES); \
+      hipFuncSetAttribute((const void*)gemm_bf16_w256<TA_, TB_, OF_, EP_>, hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS_BYTES); \
       attr_set = true;                                                                                                     \
     }                                                                                                                      \
-    hipLaunchKernelGGL((gemm_bf16_w256<TA_, TB_, OF_>), grid, block, W_LDS_BYTES, st, p);                                  \
+    hipLaunchKernelGGL((gemm_bf16_w256<TA_, TB_, OF_, EP_>), grid, block, W_LDS_BYTES, st, p);                                  \
   } while (0)
-  if (!ta && !tb) { if (out_f32) LAUNCH_W(false, false, true); else LAUNCH_W(false, false, false); }
-  else if (!ta && tb) { if (out_f32) LAUNCH_W(false, true, true); else LAUNCH_W(false, true, false); }
-  else if (ta && tb) { if (out_f32) LAUNCH_W(true, true, true); else LAUNCH_W(true, true, false); }
-  else { if (out_f32) LAUNCH_W(true, false, true); else LAUNCH_W(true, false, false); }
+  const int epi = (p.flags & PERO_GEMM_ROWDOT) ? 2 : (p.flags & PERO_GEMM_COLSUM) ? 1 : 0;
+  if (epi) {
+    // the fused row dots exist for the K-contiguous bf16 products only; the column-sum mode (EPI 1) is not instantiated:
+    // its per-tile atomics stall the persistent loop (see gemm.hip) - gemm_bf16_v256 takes those products
+    if (ta || tb || out_f32 || epi == 1) return false;
+    LAUNCH_W(false, false, false, 2);
+    return true;
+  }
+  if (!ta && !tb) { if (out_f32) LAUNCH_W(false, false, true, 0); else LAUNCH_W(false, false, false, 0); }
+  else if (!ta && tb) { if (out_f32) LAUNCH_W(false, true, true, 0); else LAUNCH_W(false, true, false, 0); }
+  else if (ta && tb) { if (out_f32) LAUNCH_W(true, true, true, 0); else LAUNCH_W(true, true, false, 0); }
+  else { if (out_f32) LAUNCH_W(true, false, true, 0); else LAUNCH_W(true, false, false, 0); }
 #undef LAUNCH_W
   return true;
 }
