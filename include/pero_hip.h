@@ -45,6 +45,10 @@ extern "C" {
                                  * is an OUTPUT (f32 [M][N/128]): bias[m][b] = sum over columns 128b..128b+127 of C[m][c] * gate[m][c],
                                  * with C as stored (bf16).  The attention backward's D = rowsum(dO * O) per head, out of the
                                  * epilogue of the product that writes dO.  No input bias / gate in this mode. */
+#define PERO_GEMM_RELU_BITS 8192 /* the ReLU gate as a BIT MASK, bit (n & 7) of byte gate[m * ldg + n / 8] (ldg in bytes).  With
+                                   PERO_GEMM_RELU `gate` is an OUTPUT: bit = (stored C[m][n] > 0); without it `gate` is that mask
+                                   as INPUT and replaces the bf16 gate matrix (1/16 of its bytes).  bf16 C, batch 1, the 256-row
+                                   tile kernels only (M % 256 == 0, N % 128 == 0, K % 32 == 0): anything else is PERO_E_INVALID */
 #define PERO_GEMM_COLSUM 1024   /* `bias` is an OUTPUT (f32 [N], accumulated atomically): column sums over the M rows of the
                                  * stored result - the bias gradient of the Linear whose output gradient this product
                                  * writes (replaces a separate pero_colsum pass over C).  No input bias in this mode. */

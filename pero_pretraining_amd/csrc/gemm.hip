@@ -443,7 +443,7 @@ static int gemm_dispatch(const void* A, const void* B, void* C, const float* bia
               lda % 8 == 0 && ldb % 8 == 0 && (ldc * esz_o) % 16 == 0 && aligned16(A) && aligned16(B) && aligned16(C) &&
               (sAo % 8 == 0) && (sAi % 8 == 0) && (sBo % 8 == 0) && (sBi % 8 == 0) && ((sCo * esz_o) % 16 == 0) &&
               ((sCi * esz_o) % 16 == 0) && (!residual || (ldr % 8 == 0 && aligned16(residual))) &&
-              (!gate || (ldg % 8 == 0 && aligned16(gate))) && (!(residual || gate) || out_dtype == PERO_BF16 || true);
+              (!gate || (flags & PERO_GEMM_RELU_BITS) || (ldg % 8 == 0 && aligned16(gate))) && (!(residual || gate) || out_dtype == PERO_BF16 || true);
   if (fast && !(flags & (PERO_GEMM_TILE128 | PERO_GEMM_TILE256 | PERO_GEMM_TILE_S))) {
     if (g_gemm_policy == 1) flags |= PERO_GEMM_TILE128;
     else if (g_gemm_policy == 2) flags |= PERO_GEMM_TILE256;
@@ -452,6 +452,14 @@ static int gemm_dispatch(const void* A, const void* B, void* C, const float* bia
     pc.flags = flags | cs_bits;
   }
   const bool forced0 = flags & (PERO_GEMM_TILE128 | PERO_GEMM_TILE256 | PERO_GEMM_TILE_S);
+  if (flags & PERO_GEMM_RELU_BITS) {
+    // bit-mask ReLU gate: only the w256 / v256 / r256 epilogues read or write it, and the default policy reaches one of
+    // them exactly under these conditions
+    PERO_REQUIRE(fast && gate && batch == 1 && out_dtype == PERO_BF16 && !ta && !(flags & PERO_GEMM_ATOMIC) && !forced0 && M % 256 == 0 &&
+                 N % 128 == 0 && K % 32 == 0 && !(flags & PERO_GEMM_ROWDOT) &&
+                 (g_gemm_policy == 0 || g_gemm_policy == 7 || g_gemm_policy == 10 || g_gemm_policy == 12),
+                 "pero_gemm: PERO_GEMM_RELU_BITS needs a bf16 product for the 256-row tile kernels (M %% 256, N %% 128, K %% 32, batch 1)");
+  }
   if (fast) {
     // tile-size / split-K policy.  256x256 tiles halve the L2->LDS bytes per flop; they need ~a CU-count of work
     // items.  k_split == 0 (with PERO_GEMM_ATOMIC) lets the library choose the split.

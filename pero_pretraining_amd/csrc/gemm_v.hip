@@ -195,7 +195,21 @@ __global__ __launch_bounds__(1024, 4) void gemm_bf16_v256(GemmP p, int ks_xcd) {
 #pragma unroll
         for (int e = 0; e < 8; e++) v[e] = fmaxf(v[e], 0.f);
       }
-      if (p.gate) {
+      if (p.gate && (p.flags & PERO_GEMM_RELU_BITS)) {
+        // the ReLU gate as bits: one byte per thread (its 8 columns) and row
+        unsigned char* gb = (unsigned char*)p.gate + grow * p.ldg + ((tn0 + c8) >> 3);
+        if (p.flags & PERO_GEMM_RELU) {
+          unsigned m = 0;
+#pragma unroll
+          for (int e = 0; e < 8; e++) m |= (bf2f(f2bf(v[e])) > 0.f ? 1u : 0u) << e;
+          *gb = (unsigned char)m;
+        } else {
+          const unsigned m = *gb;
+#pragma unroll
+          for (int e = 0; e < 8; e++)
+            if (!((m >> e) & 1)) v[e] = 0.f;
+        }
+      } else if (p.gate) {
         const uint4 gg = *(const uint4*)((const bf16raw*)p.gate + coff + grow * p.ldg + tn0 + c8);
         const unsigned w[4] = {gg.x, gg.y, gg.z, gg.w};
 #pragma unroll

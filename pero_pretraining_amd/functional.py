@@ -35,11 +35,17 @@ def ensure_grad(p):
 
 FWD_TILE_FLAGS = GEMM_TILE_V
 DX_ON_WT = True          # input gradients on transposed weight copies (lowp.weight_t)
-DX_TILE_FLAGS = GEMM_TILE_V  # forward products run alone on the GPU (no side-stream kernels beside them): 256x256x64 tiles
+DX_TILE_FLAGS = GEMM_TILE_V
+RELU_GATE_BITS = True    # linear1's ReLU leaves a bit mask; linear2's input gradient reads it instead of the hidden activation  # forward products run alone on the GPU (no side-stream kernels beside them): 256x256x64 tiles
 
 
-def linear_fwd(x, w, b, dtype, residual=None, relu=False, out_dtype=None):
-    return ops.gemm(x, lowp.weight(w, dtype), bias=None if b is None else b.detach(), residual=residual, relu=relu,
+def relu_bits_ok(m, n, k, dtype):
+    """Shapes for which the ReLU of a Linear can leave its gate as a bit mask (PERO_GEMM_RELU_BITS: the 256-row tile kernels)."""
+    return RELU_GATE_BITS and dtype == torch.bfloat16 and m % 256 == 0 and n % 128 == 0 and k % 32 == 0
+
+
+def linear_fwd(x, w, b, dtype, residual=None, relu=False, out_dtype=None, relu_bits=None):
+    return ops.gemm(x, lowp.weight(w, dtype), relu_bits=relu_bits, bias=None if b is None else b.detach(), residual=residual, relu=relu,
                     out_dtype=out_dtype, extra_flags=FWD_TILE_FLAGS)
 
 
@@ -108,7 +114,7 @@ class SideStream:
 
 
 def linear_bwd(dy, x, w, b, dtype, need_dx=True, gate=None, residual=None, bias_grad_done=False, side=None, dx_colsum_into=None,
-               dx_rowdot=None):
+               dx_rowdot=None, gate_bits=None):
     """dy (M,N), x (M,K), w (N,K).  Accumulates dW (+db) into .grad; returns dx = dy @ W (+residual)(*gate>0).
     dx_colsum_into: f32 [K] that receives the column sums of dx (the bias gradient of the Linear that produced x), fused
     into the dX product's epilogue.  dx_rowdot = (y, out): per-128-column-block row dots of dx with y (the attention backward's D
@@ -129,8 +135,10 @@ def linear_bwd(dy, x, w, b, dtype, need_dx=True, gate=None, residual=None, bias_
         return None
     if DX_ON_WT and dtype == torch.bfloat16:
         # dX = dY (W^T)^T on a transposed bf16 weight copy: both operands K-contiguous, 256x256x64 tiles
-        return ops.gemm(dy, lowp.weight_t(w), residual=residual, gate=gate, colsum_into=dx_colsum_into, rowdot=dx_rowdot,
-                        extra_flags=DX_TILE_FLAGS)
+        return ops.gemm(dy, lowp.weight_t(w), residual=residual, gate=None if gate_bits is not None else gate,
+                        relu_bits=gate_bits, colsum_into=dx_colsum_into, rowdot=dx_rowdot, extra_flags=DX_TILE_FLAGS)
+    if gate_bits is not None:
+        raise RuntimeError("linear_bwd: a bit-mask gate needs the bf16 transposed-weight path")
     return ops.gemm(dy, lowp.weight(w, dtype).view(w.shape[0], -1), trans_b=True, residual=residual, gate=gate,
                     colsum_into=dx_colsum_into, rowdot=dx_rowdot)
 
@@ -186,22 +194,26 @@ def layer_fwd(t, L, n, s, h, dtype, save):
         a, p = attention_fwd(qkv, n, s, h)             # p = probabilities (N*h, S, S)
     y1 = linear_fwd(a, at.out_proj.weight, at.out_proj.bias, dtype, residual=t)
     t1, mean1, rstd1 = ops.layernorm_fwd(y1, L.norm1.weight.detach(), L.norm1.bias.detach(), L.norm1.eps)
-    hdn = linear_fwd(t1, L.linear1.weight, L.linear1.bias, dtype, relu=True)
+    bits = None
+    if save and DX_ON_WT and relu_bits_ok(t1.shape[0], L.linear1.weight.shape[0], t1.shape[1], dtype) and \
+            relu_bits_ok(t1.shape[0], L.linear1.weight.shape[0], L.linear2.weight.shape[0], dtype):
+        bits = torch.empty((t1.shape[0], L.linear1.weight.shape[0] // 8), device=t1.device, dtype=torch.uint8)
+    hdn = linear_fwd(t1, L.linear1.weight, L.linear1.bias, dtype, relu=True, relu_bits=bits)
     y2 = linear_fwd(hdn, L.linear2.weight, L.linear2.bias, dtype, residual=t1)
     t2, mean2, rstd2 = ops.layernorm_fwd(y2, L.norm2.weight.detach(), L.norm2.bias.detach(), L.norm2.eps)
-    saved = (t, qkv, p, a, y1, mean1, rstd1, t1, hdn, y2, mean2, rstd2) if save else None
+    saved = (t, qkv, p, a, y1, mean1, rstd1, t1, hdn, y2, mean2, rstd2, bits) if save else None
     return t2, saved
 
 
 def layer_bwd(dt2, L, saved, n, s, h, dtype, side=None):
-    t, qkv, p, a, y1, mean1, rstd1, t1, hdn, y2, mean2, rstd2 = saved
+    t, qkv, p, a, y1, mean1, rstd1, t1, hdn, y2, mean2, rstd2, bits = saved
     at = L.self_attn
     # LN2 (its dx column sums are linear2's bias gradient)
     dy2 = ops.layernorm_bwd(dt2, y2, mean2, rstd2, L.norm2.weight.detach(), ensure_grad(L.norm2.weight),
                             ensure_grad(L.norm2.bias), ensure_grad(L.linear2.bias))
     # linear1's bias gradient = column sums of dpre1: accumulated by the epilogue of the product that writes dpre1
     fuse_b1 = FUSE_BIAS_GRAD and dtype == torch.bfloat16 and L.linear1.bias is not None and L.linear1.bias.requires_grad
-    dpre1 = linear_bwd(dy2, hdn, L.linear2.weight, L.linear2.bias, dtype, gate=hdn, bias_grad_done=True, side=side,
+    dpre1 = linear_bwd(dy2, hdn, L.linear2.weight, L.linear2.bias, dtype, gate=hdn, gate_bits=bits, bias_grad_done=True, side=side,
                        dx_colsum_into=ensure_grad(L.linear1.bias) if fuse_b1 else None)
     dt1 = linear_bwd(dpre1, t1, L.linear1.weight, L.linear1.bias, dtype, residual=dy2, side=side, bias_grad_done=fuse_b1)
     dy1 = ops.layernorm_bwd(dt1, y1, mean1, rstd1, L.norm1.weight.detach(), ensure_grad(L.norm1.weight),

@@ -535,3 +535,31 @@ def test_transpose_multi_and_transposed_weight_copies():
     with torch.no_grad():
         p.mul_(2.0)
     assert torch.equal(lowp.weight_t(p), p.detach().to(torch.bfloat16).view(256, 192).t())
+
+
+@pytest.mark.parametrize("M,N,K", [(512, 256, 192), (256, 128, 64), (1024, 2048, 512)])
+def test_gemm_relu_gate_as_bit_mask(M, N, K):
+    """PERO_GEMM_RELU_BITS: the ReLU product leaves bit (n & 7) of byte [m][n / 8] = (stored value > 0); the gated product
+    reads that mask instead of the bf16 activation - same bytes out as with the bf16 gate (w256 / v256 / r256 epilogues)."""
+    from pero_pretraining_amd import _lib, ops
+    torch.manual_seed(M + N)
+    x = (torch.randn(M, K, device="cuda") * 0.5).to(torch.bfloat16)
+    w = (torch.randn(N, K, device="cuda") * 0.2).to(torch.bfloat16)
+    b = torch.randn(N, device="cuda")
+    dy = (torch.randn(M, K, device="cuda") * 0.5).to(torch.bfloat16)
+    wt = (torch.randn(N, K, device="cuda") * 0.2).to(torch.bfloat16)  # (in = N, out = K) transposed copy of the next weight
+    for tile_flags in (0, _lib.GEMM_TILE_V):
+        bits = torch.zeros((M, N // 8), device="cuda", dtype=torch.uint8)
+        h = ops.gemm(x, w, bias=b, relu=True, relu_bits=bits, extra_flags=tile_flags)
+        h_ref = ops.gemm(x, w, bias=b, relu=True, extra_flags=tile_flags)
+        assert torch.equal(h, h_ref)
+        want = np.packbits((h.float() > 0).cpu().numpy(), axis=1, bitorder="little")
+        assert np.array_equal(bits.cpu().numpy(), want)
+        cs_a = torch.zeros(N, device="cuda"); cs_b = torch.zeros(N, device="cuda")
+        for kw_a, kw_b in (({}, {}), ({"colsum_into": cs_a}, {"colsum_into": cs_b})):
+            got = ops.gemm(dy, wt, relu_bits=bits, extra_flags=tile_flags, **kw_a)
+            ref = ops.gemm(dy, wt, gate=h, extra_flags=tile_flags, **kw_b)
+            assert torch.equal(got, ref)
+        assert torch.allclose(cs_a, cs_b, rtol=1e-5, atol=1e-4)
+    with pytest.raises(RuntimeError):  # shapes outside the 256-row tile kernels are refused, not silently ungated
+        ops.gemm(dy[:128], wt, relu_bits=bits[:128])

@@ -22,7 +22,19 @@ wot = (torch.randn(512, 512, device="cuda") * 0.05).bfloat16()
 o = torch.randn(M, 512, device="cuda").bfloat16()
 dots = torch.empty(M, 4, device="cuda")
 da = torch.empty(M, 512, device="cuda", dtype=torch.bfloat16)
+bits = torch.zeros(M, 256, device="cuda", dtype=torch.uint8)
+ops.gemm((torch.randn(M, 512, device="cuda") * 0.5).bfloat16(), (torch.randn(2048, 512, device="cuda") * 0.05).bfloat16(), relu=True,
+         relu_bits=bits, extra_flags=_lib.GEMM_TILE_V)
+res512 = torch.randn(M, 512, device="cuda").bfloat16()
+w2 = (torch.randn(512, 2048, device="cuda") * 0.05).bfloat16()
+y512 = torch.empty(M, 512, device="cuda", dtype=torch.bfloat16)
 cases = {
+    "linear2 fwd + residual [65536x512x2048]": lambda: ops.gemm(h, w2, out=y512, residual=res512, extra_flags=_lib.GEMM_TILE_V),
+    "linear2 fwd plain": lambda: ops.gemm(h, w2, out=y512, extra_flags=_lib.GEMM_TILE_V),
+    "out_proj fwd + residual [65536x512x512]": lambda: ops.gemm(dy, wot, out=da, residual=res512, extra_flags=_lib.GEMM_TILE_V),
+    "linear2 dX plain [65536x2048x512]": lambda: ops.gemm(dy, w2t, out=dx, extra_flags=_lib.GEMM_TILE_V),
+    "linear2 dX BIT gate+colsum": lambda: ops.gemm(dy, w2t, out=dx, relu_bits=bits, colsum_into=cs, extra_flags=_lib.GEMM_TILE_V),
+    "linear2 dX BIT gate only": lambda: ops.gemm(dy, w2t, out=dx, relu_bits=bits, extra_flags=_lib.GEMM_TILE_V),
     "linear2 dX gate+colsum [65536x2048x512]": lambda: ops.gemm(dy, w2t, out=dx, gate=h, colsum_into=cs, extra_flags=_lib.GEMM_TILE_V),
     "linear2 dX gate only": lambda: ops.gemm(dy, w2t, out=dx, gate=h, extra_flags=_lib.GEMM_TILE_V),
     "out_proj dX rowdot [65536x512x512]": lambda: ops.gemm(dy, wot, out=da, rowdot=(o, dots), extra_flags=_lib.GEMM_TILE_V),
