@@ -150,6 +150,15 @@ __global__ __launch_bounds__(1024, 4) void gemm_bf16_v256(GemmP p, int ks_xcd) {
 #pragma unroll
   for (int e = 0; e < 8; e++) bias[e] = (p.bias && !colsum) ? p.bias[tn0 + c8 + e] : 0.f;
   float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  // bit-mask gate: the tile's eight mask bytes of this thread are fetched HERE, ahead of the staging barriers - loaded where
+  // they are used (like the bf16 gate rows) each of the eight dependent loads per tile exposed its full latency
+  const bool bits_in = p.gate && (p.flags & PERO_GEMM_RELU_BITS) && !(p.flags & PERO_GEMM_RELU);
+  unsigned gbits[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+  if (bits_in) {
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+      gbits[i] = *((const unsigned char*)p.gate + (tm0 + (i >> 1) * 64 + (tid >> 5) + 32 * (i & 1)) * p.ldg + ((tn0 + c8) >> 3));
+  }
 #pragma unroll
   for (int qq = 0; qq < 4; qq++) {
     lds_barrier();
@@ -204,7 +213,7 @@ __global__ __launch_bounds__(1024, 4) void gemm_bf16_v256(GemmP p, int ks_xcd) {
           for (int e = 0; e < 8; e++) m |= (bf2f(f2bf(v[e])) > 0.f ? 1u : 0u) << e;
           *gb = (unsigned char)m;
         } else {
-          const unsigned m = *gb;
+          const unsigned m = gbits[qq * 2 + rr];
 #pragma unroll
           for (int e = 0; e < 8; e++)
             if (!((m >> e) & 1)) v[e] = 0.f;

@@ -176,6 +176,13 @@ __global__ __launch_bounds__(1024, 4) void gemm_bf16_w256(GemmP p) {
 #pragma unroll
     for (int e = 0; e < 8; e++) bias[e] = (EPI == 0 && p.bias) ? p.bias[tn0 + c8e + e] : 0.f;
     float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // EPI 3, mask as input: this thread's eight mask bytes of the tile, fetched ahead of the staging barriers (gemm_v.hip)
+    unsigned gbits[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    if (EPI == 3 && !(p.flags & PERO_GEMM_RELU)) {
+#pragma unroll
+      for (int i = 0; i < 8; i++)
+        gbits[i] = *((const unsigned char*)p.gate + (tm0 + (i >> 1) * 64 + (tid_e >> 5) + 32 * (i & 1)) * p.ldg + ((tn0 + c8e) >> 3));
+    }
 #pragma unroll
     for (int qq = 0; qq < 4; qq++) {
       if (qq > 0) lds_barrier();  // previous chunk's staging reads are done (chunk 0: the stage was released by the last mid-barrier)
@@ -232,7 +239,7 @@ __global__ __launch_bounds__(1024, 4) void gemm_bf16_w256(GemmP p) {
             for (int e = 0; e < 8; e++) m |= (bf2f(f2bf(v[e])) > 0.f ? 1u : 0u) << e;
             *gb = (unsigned char)m;
           } else {
-            const unsigned m = *gb;
+            const unsigned m = gbits[qq * 2 + rr];
 #pragma unroll
             for (int e = 0; e < 8; e++)
               if (!((m >> e) & 1)) v[e] = 0.f;
