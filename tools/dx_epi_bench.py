@@ -28,7 +28,15 @@ ops.gemm((torch.randn(M, 512, device="cuda") * 0.5).bfloat16(), (torch.randn(204
 res512 = torch.randn(M, 512, device="cuda").bfloat16()
 w2 = (torch.randn(512, 2048, device="cuda") * 0.05).bfloat16()
 y512 = torch.empty(M, 512, device="cuda", dtype=torch.bfloat16)
+x512 = (torch.randn(M, 512, device="cuda") * 0.5).bfloat16()
+w1 = (torch.randn(2048, 512, device="cuda") * 0.05).bfloat16()
+b1 = torch.randn(2048, device="cuda")
 cases = {
+    "linear1 fwd relu [65536x2048x512]": lambda: ops.gemm(x512, w1, out=dx, bias=b1, relu=True, extra_flags=_lib.GEMM_TILE_V),
+    "linear1 fwd plain": lambda: ops.gemm(x512, w1, out=dx, extra_flags=_lib.GEMM_TILE_V),
+    "linear1 fwd bias only": lambda: ops.gemm(x512, w1, out=dx, bias=b1, extra_flags=_lib.GEMM_TILE_V),
+    "linear1 fwd relu only": lambda: ops.gemm(x512, w1, out=dx, relu=True, extra_flags=_lib.GEMM_TILE_V),
+    "linear1 fwd relu + bit mask out": lambda: ops.gemm(x512, w1, out=dx, bias=b1, relu=True, relu_bits=bits, extra_flags=_lib.GEMM_TILE_V),
     "linear2 fwd + residual [65536x512x2048]": lambda: ops.gemm(h, w2, out=y512, residual=res512, extra_flags=_lib.GEMM_TILE_V),
     "linear2 fwd plain": lambda: ops.gemm(h, w2, out=y512, extra_flags=_lib.GEMM_TILE_V),
     "out_proj fwd + residual [65536x512x512]": lambda: ops.gemm(dy, wot, out=da, residual=res512, extra_flags=_lib.GEMM_TILE_V),
