@@ -103,8 +103,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_k(const bf16raw* qkv, bf16raw
 
   for (int u = 0; u < units; u++) {
     const int head = head0 + u / nkt, kt = u % nkt;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();  // K(u), V(u) landed
+    // K(u) (and the head's Q rows) must have landed; V(u) - the NEWEST eight DMA instructions, issued at the end of the
+    // previous unit - may still fly: it is waited for after the scores, one phase later (in-order vmcnt: a full wait here
+    // exposed V's whole latency at every unit)
+    if (u > 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // K(u) landed
     f16v s[4];
 #pragma unroll
     for (int t = 0; t < 4; t++) {
@@ -113,7 +117,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_k(const bf16raw* qkv, bf16raw
       for (int ks = 0; ks < 8; ks++)
         s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(attn_k_frag(kimg, t * 32 + r, ks, h5), qf[ks], s[t], 0, 0, 0);
     }
-    __syncthreads();  // every wave is done with the K image
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // own part of V(u)
+    __syncthreads();  // every wave is done with the K image; V(u) landed
     if (u + 1 < units) {
       const int nhd = head0 + (u + 1) / nkt, nkt_i = (u + 1) % nkt;
       attn_glds_tile<false>(lbase + nhd * 128 + d + (long long)nkt_i * 128 * ld, ld, kimg, wave, lane);
