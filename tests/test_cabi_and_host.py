@@ -140,3 +140,26 @@ def test_lowp_cache_entries_die_with_their_parameter():
     q = torch.nn.Parameter(torch.ones(8))
     lowp._cache[id(q)] = (lowp._key(q), torch.zeros(8, dtype=torch.bfloat16), True, lowp.weakref.ref(torch.nn.Parameter(torch.zeros(1))))
     assert lowp._entry(q) is None          # an entry whose weak reference is not this very object is discarded
+
+
+def test_new_entry_points_validate_arguments_without_gpu():
+    """pero_transpose_multi and the PERO_GEMM_RELU_BITS contract are refused on the host side before any launch."""
+    import ctypes
+    from pero_pretraining_amd import _lib
+    L = _lib.lib()
+    assert L.pero_transpose_multi(None, None, None, 1, 1, None) < 0
+    assert b"pero_transpose_multi" in L.pero_last_error()
+    buf = (ctypes.c_uint16 * 64)()
+    tab = (ctypes.c_int64 * 5)(0, 0, 8, 8, 0)
+    assert L.pero_transpose_multi(buf, buf, tab, 0, 1, None) < 0          # no matrices
+    assert L.pero_transpose_multi(buf, buf, tab, 1, 0, None) < 0          # no tiles
+
+
+def test_masked_head_mode_is_validated_on_the_host():
+    from pero_pretraining_amd.masked_pretraining import model as M
+    bb = M.init_backbone({"type": "vit", "num_blocks": 1, "model_dim": 64, "num_heads": 1, "feedforward_dim": 64})
+    model = M.MaskedTransformerEncoder(bb, M.init_head({"type": "linear", "in_features": 64, "out_features": 32}))
+    assert model.head_rows == "all"
+    model.head_rows = "some"
+    with pytest.raises(ValueError, match="Unknown head_rows"):
+        model(torch.zeros(1, 3, 40, 16), None, None)
