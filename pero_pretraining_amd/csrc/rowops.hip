@@ -169,6 +169,85 @@ __global__ __launch_bounds__(256) void layernorm_bwd_k(const T* dy, const T* x, 
     __syncthreads();
   }
 }
+// bf16, d <= 512 (one 8-column group per lane): the same arithmetic as layernorm_bwd_k<bf16raw, 1>, software-pipelined - the raw
+// rows of the NEXT pair (x, dy: one 16-byte load each, mean, rstd) are requested before the current pair is reduced, so a
+// wave always has a pair of rows in flight (the plain loop issued its loads, waited, reduced, stored: latency-bound at 8
+// waves per CU).
+__global__ __launch_bounds__(256) void layernorm_bwd_pf_k(const bf16raw* dy, const bf16raw* x, const float* mean, const float* rstd,
+                                                          const float* gamma, bf16raw* dx, float* work, const float* dxsum,
+                                                          long long rows, int d) {
+  __shared__ float red[4][512];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = lane * 8;
+  const bool act = col < d;
+  float ag[8], ab[8], ax[8], g[8];
+#pragma unroll
+  for (int e = 0; e < 8; e++) { ag[e] = 0.f; ab[e] = 0.f; ax[e] = 0.f; g[e] = 0.f; }
+  if (act) load8<float>(gamma + col, g);
+  const long long stride = (long long)gridDim.x * 4;
+  long long row0 = (long long)blockIdx.x * 4 + wave;
+  uint4 nx[2], nd[2];
+  float nmu[2] = {0.f, 0.f}, nrs[2] = {0.f, 0.f};
+  nx[0] = nx[1] = nd[0] = nd[1] = make_uint4(0, 0, 0, 0);
+  auto fetch = [&](long long r0) {
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const long long r = r0 + u * stride;
+      if (r < rows) {
+        nmu[u] = mean[r]; nrs[u] = rstd[r];
+        if (act) { nx[u] = *(const uint4*)(x + r * d + col); nd[u] = *(const uint4*)(dy + r * d + col); }
+      }
+    }
+  };
+  if (row0 < rows) fetch(row0);
+  for (; row0 < rows; row0 += 2 * stride) {
+    const bool has[2] = {true, row0 + stride < rows};
+    uint4 cx[2] = {nx[0], nx[1]}, cd[2] = {nd[0], nd[1]};
+    const float mu[2] = {nmu[0], nmu[1]}, rs[2] = {nrs[0], nrs[1]};
+    if (row0 + 2 * stride < rows) fetch(row0 + 2 * stride);
+    float xh[2][8], gy[2][8], s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      if (!has[u] || !act) continue;
+      const unsigned wx[4] = {cx[u].x, cx[u].y, cx[u].z, cx[u].w}, wd[4] = {cd[u].x, cd[u].y, cd[u].z, cd[u].w};
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        const float xv = (e & 1) ? __uint_as_float(wx[e >> 1] & 0xffff0000u) : __uint_as_float(wx[e >> 1] << 16);
+        const float dv = (e & 1) ? __uint_as_float(wd[e >> 1] & 0xffff0000u) : __uint_as_float(wd[e >> 1] << 16);
+        xh[u][e] = (xv - mu[u]) * rs[u];
+        gy[u][e] = dv * g[e];
+        s1[u] += gy[u][e];
+        s2[u] += gy[u][e] * xh[u][e];
+        ag[e] += dv * xh[u][e];
+        ab[e] += dv;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      s1[0] += __shfl_xor(s1[0], o, 64); s2[0] += __shfl_xor(s2[0], o, 64);
+      s1[1] += __shfl_xor(s1[1], o, 64); s2[1] += __shfl_xor(s2[1], o, 64);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      if (!has[u] || !act) continue;
+      const float c1 = s1[u] / (float)d, c2 = s2[u] / (float)d;
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; e++) { o[e] = rs[u] * (gy[u][e] - c1 - xh[u][e] * c2); ax[e] += o[e]; }
+      store8<bf16raw>(dx + (row0 + u * stride) * d + col, o);
+    }
+  }
+#pragma unroll
+  for (int which = 0; which < 3; which++) {
+    if (which == 2 && !dxsum) break;
+#pragma unroll
+    for (int e = 0; e < 8; e++) red[wave][col + e] = which == 0 ? ag[e] : (which == 1 ? ab[e] : ax[e]);
+    __syncthreads();
+    float* dst = work + ((long long)which * gridDim.x + blockIdx.x) * d;
+    for (int c = threadIdx.x; c < d; c += 256) dst[c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+    __syncthreads();
+  }
+}
 __global__ __launch_bounds__(256) void layernorm_bwd_reduce_k(const float* work, float* dgamma, float* dbeta, float* dxsum,
                                                               int nblocks, int d) {
   // block = 64 columns x 4 slices of the partial-sum rows; 8 independent loads in flight per thread
@@ -214,7 +293,10 @@ static int ln_dispatch_bwd(const void* dy, const void* x, const float* mean, con
   dim3 grid((unsigned)blocks), block(256);
   const int nch = (int)((d + 511) / 512);
 #define LN_B(N_) hipLaunchKernelGGL((layernorm_bwd_k<T, N_>), grid, block, 0, st, (const T*)dy, (const T*)x, mean, rstd, gamma, (T*)dx, work, dxsum, (long long)rows, (int)d)
-  if (nch == 1) LN_B(1); else if (nch == 2) LN_B(2); else LN_B(4);
+  if (nch == 1 && sizeof(T) == 2)
+    hipLaunchKernelGGL(layernorm_bwd_pf_k, grid, block, 0, st, (const bf16raw*)dy, (const bf16raw*)x, mean, rstd, gamma, (bf16raw*)dx, work, dxsum,
+                       (long long)rows, (int)d);
+  else if (nch == 1) LN_B(1); else if (nch == 2) LN_B(2); else LN_B(4);
 #undef LN_B
   hipLaunchKernelGGL(layernorm_bwd_reduce_k, dim3((unsigned)((d + 63) / 64), 3), dim3(256), 0, st, work, dgamma, dbeta, dxsum, (int)blocks, (int)d);
   return 0;
