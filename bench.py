@@ -119,7 +119,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("PERO_BENCH_BATCH", 256)), help="lines per GPU")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("PERO_BENCH_BATCH", 512)), help="lines per GPU")
     ap.add_argument("--no-side-stream", action="store_true", help="weight gradients on the main stream (clean per-kernel profiles)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
