@@ -457,7 +457,7 @@ static int gemm_dispatch(const void* A, const void* B, void* C, const float* bia
     // them exactly under these conditions
     PERO_REQUIRE(fast && gate && batch == 1 && out_dtype == PERO_BF16 && !ta && !(flags & PERO_GEMM_ATOMIC) && !forced0 && M % 256 == 0 &&
                  N % 128 == 0 && K % 32 == 0 && !(flags & PERO_GEMM_ROWDOT) &&
-                 (g_gemm_policy == 0 || g_gemm_policy == 7 || g_gemm_policy == 10 || g_gemm_policy == 12),
+                 (g_gemm_policy == 0 || g_gemm_policy == 7 || g_gemm_policy == 10 || g_gemm_policy == 11 || g_gemm_policy == 12),
                  "pero_gemm: PERO_GEMM_RELU_BITS needs a bf16 product for the 256-row tile kernels (M %% 256, N %% 128, K %% 32, batch 1)");
   }
   if (fast) {
@@ -548,11 +548,13 @@ static int gemm_dispatch(const void* A, const void* B, void* C, const float* bia
       PERO_CHECK_LAUNCH("pero_gemm(bf16 q256)");
       return PERO_OK;
     }
-    if ((g_gemm_policy == 7 || g_gemm_policy == 0 || g_gemm_policy == 11 || g_gemm_policy == 15) && !forced0 && !atomic && pero_launch_gemm_r256(want_cs ? pc : p, batch, k_split, ta, tb, out_dtype == PERO_F32, st)) {
+    // (a bit-mask gate that the 256x256 kernels above declined always ends here, whatever the policy: only these epilogues know it)
+    if ((g_gemm_policy == 7 || g_gemm_policy == 0 || g_gemm_policy == 11 || g_gemm_policy == 15 || (flags & PERO_GEMM_RELU_BITS)) && !forced0 && !atomic && pero_launch_gemm_r256(want_cs ? pc : p, batch, k_split, ta, tb, out_dtype == PERO_F32, st)) {
       *colsum_fused = want_cs;
       PERO_CHECK_LAUNCH("pero_gemm(bf16 r256)");
       return PERO_OK;
     }
+    PERO_REQUIRE(!(flags & PERO_GEMM_RELU_BITS), "pero_gemm: no kernel took the PERO_GEMM_RELU_BITS product (internal)");
     if (flags & PERO_GEMM_TILE256) use256 = can256;
     // default for non-atomic products (measured, M = 32768): the four-workgroups-per-CU 128x128x32 kernel wins on
     // every shape of the step except long-K products with a small output (K >= 2048), where the 256 tile wins

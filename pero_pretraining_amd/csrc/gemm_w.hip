@@ -174,7 +174,7 @@ __global__ __launch_bounds__(1024, 4) void gemm_bf16_w256(GemmP p) {
     const int c8e = (tid_e & 31) * 8;
     float bias[8];
 #pragma unroll
-    for (int e = 0; e < 8; e++) bias[e] = (EPI == 0 && p.bias) ? p.bias[tn0 + c8e + e] : 0.f;
+    for (int e = 0; e < 8; e++) bias[e] = ((EPI == 0 || EPI == 3) && p.bias) ? p.bias[tn0 + c8e + e] : 0.f;  // (modes 1, 2: p.bias is an output)
     float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     // EPI 3, mask as input: this thread's eight mask bytes of the tile, fetched ahead of the staging barriers (gemm_v.hip)
     unsigned gbits[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
