@@ -117,8 +117,9 @@ def test_config2_topk_error_counters_monotone(cfg2):
     assert c[0] == int(mask.sum()) and c[1] >= c[2] >= c[3] >= c[4] > 0
 
 
-def test_bench_scale_step_equals_the_weighted_sum_of_its_sub_batches():
-    """B = 256 lines (M = 65 536 token rows: the persistent 256x256x64 products with every epilogue mode, the bit-mask ReLU
+@pytest.mark.parametrize("B", [256, 512])
+def test_bench_scale_step_equals_the_weighted_sum_of_its_sub_batches(B):
+    """B = 256 / 512 lines (512 = bench.py's default; M = 65 536 / 131 072 token rows: the persistent 256x256x64 products with every epilogue mode, the bit-mask ReLU
     gate, transposed-weight input gradients, long split-K weight gradients) against the SAME lines in 16-line sub-batches
     (the 256x128x32 / 128x128 kernels that the oracle tests pin).  Lines are independent, so the logits must agree row by
     row, the loss is the masked-count-weighted mean of the sub-batch losses and every gradient the same weighted sum."""
@@ -127,7 +128,7 @@ def test_bench_scale_step_equals_the_weighted_sum_of_its_sub_batches():
     torch.manual_seed(1)
     model = M.MaskedTransformerEncoder(M.init_backbone(dict(CFG2_BB)), M.init_head(dict(CFG2_HD))).cuda().train()
     rng = np.random.default_rng(77)
-    B, sub = 256, 16
+    sub = 16
     images = torch.from_numpy(rng.integers(0, 256, (B, 40, 2048, 3), dtype=np.uint8)).cuda()
     labels = torch.from_numpy(rng.integers(0, 4096, (B, 256))).cuda()
     mask = torch.from_numpy((rng.random((B, 256)) < 0.15).astype(np.int64)).cuda()
@@ -161,3 +162,44 @@ def test_bench_scale_step_equals_the_weighted_sum_of_its_sub_batches():
         assert err <= 2e-2 * max(float(want.abs().max()), 1e-8), (k, err, float(want.abs().max()))
         rel_l2 = float((g_full[k] - want).norm() / want.norm().clamp_min(1e-12))
         assert rel_l2 <= 2e-2, (k, rel_l2)
+
+
+def test_bench_scale_joint_step_equals_its_sub_batches():
+    """Config 5 shape on one GPU (NT-Xent, 128 line pairs = 256 lines through the 12-layer backbone as ONE batch of views, linear
+    head 512 -> 4096): per-line embeddings and the per-line loss decompose over sub-batches of 16 pairs exactly like the
+    masked step (the loss is a mean over lines, so weights are 1 / 8)."""
+    import pero_pretraining_amd as P
+    from pero_pretraining_amd.joint_embedding_pretraining import model as J
+    from pero_pretraining_amd.joint_embedding_pretraining.losses import NTXentLoss
+    torch.manual_seed(2)
+    model = J.JointEmbeddingTransformerEncoder(J.init_backbone(dict(CFG2_BB)), J.init_head({"type": "linear", "in_features": 512, "out_features": 4096}),
+                                               NTXentLoss()).cuda().train()
+    rng = np.random.default_rng(5)
+    B, sub = 128, 16
+    im1 = torch.from_numpy(rng.integers(0, 256, (B, 40, 2048, 3), dtype=np.uint8)).cuda()
+    im2 = torch.from_numpy(rng.integers(0, 256, (B, 40, 2048, 3), dtype=np.uint8)).cuda()
+    ones = torch.ones((B, 256), dtype=torch.uint8, device="cuda")
+    model.backbone.position_model.random_shift = False   # fixed positional rows: the two views draw offsets separately otherwise
+
+    def step(sl):
+        model.zero_grad()
+        with P.autocast(True):
+            res = model(im1[sl], im2[sl], ones[sl], ones[sl], ones[sl], ones[sl])
+        res["loss"].backward()
+        return res["output1"].detach().float(), res["output2"].detach().float(), float(res["loss"]), \
+            {k: p.grad.detach().float().clone() for k, p in model.named_parameters()}
+
+    o1, o2, loss_full, g_full = step(slice(0, B))
+    acc, loss_acc = None, 0.0
+    for s0 in range(0, B, sub):
+        sl = slice(s0, s0 + sub)
+        a1, a2, loss, g = step(sl)
+        w = sub / B
+        loss_acc += w * loss
+        acc = {k: w * v for k, v in g.items()} if acc is None else {k: acc[k] + w * g[k] for k in g}
+        for a, o in ((a1, o1[sl]), (a2, o2[sl])):
+            assert float((a - o).abs().max()) <= 1.6e-2 * float(o.abs().max()), s0
+    assert abs(loss_acc - loss_full) <= 1e-4 * abs(loss_full)
+    for k, want in acc.items():
+        rel_l2 = float((g_full[k] - want).norm() / want.norm().clamp_min(1e-12))
+        assert rel_l2 <= 3e-2, (k, rel_l2)
