@@ -144,6 +144,18 @@ def test_bench_scale_step_equals_the_weighted_sum_of_its_sub_batches(B):
 
     out_full, loss_full, g_full = step(slice(0, B))
     n_full = int(mask.sum())
+    # the optional head-on-masked-rows path at this size: the same loss and gradients as the all-positions step
+    model.head_rows = "masked"
+    model.zero_grad()
+    model.backbone.set_offsets(offs)
+    with P.autocast(True):
+        res = model(images, labels, mask)
+    res["loss"].backward()
+    model.head_rows = "all"
+    assert res["output"] is None and abs(float(res["loss"]) - loss_full) <= 1e-5 * abs(loss_full)
+    for k, p in model.named_parameters():
+        rel = float((p.grad.float() - g_full[k]).norm() / g_full[k].norm().clamp_min(1e-12))
+        assert rel <= 2e-3, (k, rel)
     acc, loss_acc = None, 0.0
     for s0 in range(0, B, sub):
         sl = slice(s0, s0 + sub)
