@@ -370,6 +370,9 @@ __global__ __launch_bounds__(256) void gemm_generic(GemmP p) {
 //   gradients, 15 = x256 (four waves, 128x128 wave tiles, NT only).  Measurements: DESIGN.md section 8.
 static int g_gemm_policy = 0;
 static int g_splitk_items = 512;     // workgroups the automatic split-K aims for (k_split = 0)
+static int g_splitk_t256_min = 8;    // > 0: split-K weight gradients with at least this many 256x256 output tiles and a reduction of >= 131072
+                                     // rows take gemm_bf16_v256 (256x256x64 tiles, one k-slice round): step 48.9 -> 47.7 ms at 512 lines per GPU;
+                                     // shorter reductions (<= 256 lines) stay on the 128x128 kernel, which is 0.4 - 3 % faster there
 static int g_splitk_nearest = 0;    // 1: k-slice count rounded to the nearest multiple of 8 instead of up (faster alone for the
                                     // 48-tile in_proj gradient, 0.1 ms slower inside the step: tools/splitk_ab.py)
 static int g_gemm_persistent = 1;  // PERO_GEMM_TILE_V products: persistent w256 (epilogue under the next tile's first stage) instead of v256
@@ -378,6 +381,7 @@ extern "C" int pero_set_option(const char* name, int value) {
   if (name && !strcmp(name, "gemm_policy")) { g_gemm_policy = value; return PERO_OK; }
   if (name && !strcmp(name, "splitk_xcd")) { g_pero_splitk_xcd = value; return PERO_OK; }
   if (name && !strcmp(name, "splitk_nearest")) { g_splitk_nearest = value; return PERO_OK; }
+  if (name && !strcmp(name, "splitk_t256_min")) { g_splitk_t256_min = value; return PERO_OK; }
   if (name && !strcmp(name, "gemm_persistent")) { g_gemm_persistent = value; return PERO_OK; }
   if (name && !strcmp(name, "splitk_items")) { g_splitk_items = value > 0 ? value : 256; return PERO_OK; }
   pero_set_error("pero_set_option: unknown option %s", name ? name : "(null)");
@@ -501,7 +505,8 @@ static int gemm_dispatch(const void* A, const void* B, void* C, const float* bia
         return PERO_OK;
       }
     }
-    if (g_gemm_policy == 13 && atomic && can256 && !forced0 && out_dtype == PERO_F32) {  // experiment: 256x256x64 split-K tiles
+    if ((g_gemm_policy == 13 || (g_gemm_policy == 0 && g_splitk_t256_min > 0 && t256 >= g_splitk_t256_min && K >= 131072)) && atomic && can256 && !forced0 &&
+        out_dtype == PERO_F32) {  // 256x256x64 split-K tiles
       long long ks2 = k_split_req;
       if (ks2 == 0) {
         ks2 = 256 / t256;                       // one round of workgroups, slices in multiples of 8 (one per XCD)
