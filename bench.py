@@ -119,7 +119,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("PERO_BENCH_BATCH", 512)), help="lines per GPU")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("PERO_BENCH_BATCH", 1024)), help="lines per GPU")
     ap.add_argument("--no-side-stream", action="store_true", help="weight gradients on the main stream (clean per-kernel profiles)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -243,7 +243,7 @@ def main():
         fsum = sum(v[1] for v in fast.values())
         nl = sum(v[2] for v in fast.values()) or 1
         ach = fsum / tsum / 1e12
-        roofline = {"bound": "mfma", "kernel": "bf16 MFMA tile GEMM: gemm_bf16_w256 / v256 (forward and input gradients, 256x256x64) + gemm_bf16_o128 (split-K weight gradients, 128x128x64)", "achieved": round(ach, 2),
+        roofline = {"bound": "mfma", "kernel": "bf16 MFMA tile GEMM: gemm_bf16_w256 / v256 (forward, input gradients and split-K weight gradients, 256x256x64) + gemm_bf16_o128 (out_proj's weight gradient, 128x128x64)", "achieved": round(ach, 2),
                     "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4),
                     "traffic": pmc_traffic(args.batch), "launches_per_step": nl // 2, "avg_launch_us": round(tsum / nl * 1e6, 2),
                     "gflop_per_launch": round(fsum / nl / 1e9, 3),
