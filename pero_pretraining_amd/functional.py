@@ -34,6 +34,7 @@ def ensure_grad(p):
 
 
 FWD_TILE_FLAGS = GEMM_TILE_V
+FUSE_B1_COLSUM = True    # linear1's bias gradient from the epilogue of linear2's input-gradient product (else: a column-sum pass on the side stream)
 DX_ON_WT = True          # input gradients on transposed weight copies (lowp.weight_t)
 DX_TILE_FLAGS = GEMM_TILE_V
 RELU_GATE_BITS = False   # option: linear1's ReLU leaves a bit mask and linear2's input gradient reads it instead of the hidden activation
@@ -213,7 +214,7 @@ def layer_bwd(dt2, L, saved, n, s, h, dtype, side=None):
     dy2 = ops.layernorm_bwd(dt2, y2, mean2, rstd2, L.norm2.weight.detach(), ensure_grad(L.norm2.weight),
                             ensure_grad(L.norm2.bias), ensure_grad(L.linear2.bias))
     # linear1's bias gradient = column sums of dpre1: accumulated by the epilogue of the product that writes dpre1
-    fuse_b1 = FUSE_BIAS_GRAD and dtype == torch.bfloat16 and L.linear1.bias is not None and L.linear1.bias.requires_grad
+    fuse_b1 = FUSE_BIAS_GRAD and FUSE_B1_COLSUM and dtype == torch.bfloat16 and L.linear1.bias is not None and L.linear1.bias.requires_grad
     dpre1 = linear_bwd(dy2, hdn, L.linear2.weight, L.linear2.bias, dtype, gate=hdn, gate_bits=bits, bias_grad_done=True, side=side,
                        dx_colsum_into=ensure_grad(L.linear1.bias) if fuse_b1 else None)
     dt1 = linear_bwd(dpre1, t1, L.linear1.weight, L.linear1.bias, dtype, residual=dy2, side=side, bias_grad_done=fuse_b1)
