@@ -62,8 +62,9 @@ __device__ __forceinline__ void wstage_glds(const bf16raw* X, long long ld, long
 
 // EPI: 0 = bias / residual / ReLU / ReLU-gate epilogue; 1 = + column sums of the stored result accumulated into p.bias (an
 // OUTPUT then: PERO_GEMM_COLSUM); 2 = per-128-column row dots of the stored result with p.gate written to p.bias
-// ([M][N / 128] f32: PERO_GEMM_ROWDOT); 3 = the ReLU gate as a bit mask, written (with PERO_GEMM_RELU) or applied
-// (PERO_GEMM_RELU_BITS).  Modes 1 - 3 exist for the K-contiguous bf16 products only (the input-gradient
+// ([M][N / 128] f32: PERO_GEMM_ROWDOT); 3 / 4 = the ReLU gate as a bit mask (PERO_GEMM_RELU_BITS), written (with
+// PERO_GEMM_RELU) / applied - two modes so that the forward one does not carry the backward one's registers.  Modes 1 - 4
+// exist for the K-contiguous bf16 products only (the input-gradient
 // products on transposed weight copies).
 template <bool TA, bool TB, bool OUTF32, int EPI>
 __global__ __launch_bounds__(1024, 4) void gemm_bf16_w256(GemmP p) {
@@ -174,11 +175,11 @@ __global__ __launch_bounds__(1024, 4) void gemm_bf16_w256(GemmP p) {
     const int c8e = (tid_e & 31) * 8;
     float bias[8];
 #pragma unroll
-    for (int e = 0; e < 8; e++) bias[e] = ((EPI == 0 || EPI == 3) && p.bias) ? p.bias[tn0 + c8e + e] : 0.f;  // (modes 1, 2: p.bias is an output)
+    for (int e = 0; e < 8; e++) bias[e] = ((EPI == 0 || EPI == 3 || EPI == 4) && p.bias) ? p.bias[tn0 + c8e + e] : 0.f;  // (modes 1, 2: p.bias is an output)
     float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     // EPI 3, mask as input: this thread's eight mask bytes of the tile, fetched ahead of the staging barriers (gemm_v.hip)
     unsigned gbits[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
-    if (EPI == 3 && !(p.flags & PERO_GEMM_RELU)) {
+    if (EPI == 4) {
 #pragma unroll
       for (int i = 0; i < 8; i++)
         gbits[i] = *((const unsigned char*)p.gate + (tm0 + (i >> 1) * 64 + (tid_e >> 5) + 32 * (i & 1)) * p.ldg + ((tn0 + c8e) >> 3));
@@ -231,19 +232,16 @@ __global__ __launch_bounds__(1024, 4) void gemm_bf16_w256(GemmP p) {
           dot += __shfl_xor(dot, 1, 64); dot += __shfl_xor(dot, 2, 64); dot += __shfl_xor(dot, 4, 64); dot += __shfl_xor(dot, 8, 64);
           if ((tid_e & 15) == 0) ((float*)p.bias)[grow * (p.N >> 7) + (tn0 >> 7) + ((tid_e >> 4) & 1)] = dot;
         } else if (EPI == 3) {
-          // the ReLU gate as bits: one byte per thread (its 8 columns) and row
-          unsigned char* gb = (unsigned char*)p.gate + grow * p.ldg + ((tn0 + c8e) >> 3);
-          if (p.flags & PERO_GEMM_RELU) {
-            unsigned m = 0;
+          // the ReLU gate as bits, written: one byte per thread (its 8 columns) and row
+          unsigned m = 0;
 #pragma unroll
-            for (int e = 0; e < 8; e++) m |= (bf2f(f2bf(v[e])) > 0.f ? 1u : 0u) << e;
-            *gb = (unsigned char)m;
-          } else {
-            const unsigned m = gbits[qq * 2 + rr];
+          for (int e = 0; e < 8; e++) m |= (bf2f(f2bf(v[e])) > 0.f ? 1u : 0u) << e;
+          *((unsigned char*)p.gate + grow * p.ldg + ((tn0 + c8e) >> 3)) = (unsigned char)m;
+        } else if (EPI == 4) {
+          const unsigned m = gbits[qq * 2 + rr];  // ... applied: fetched ahead of the staging barriers
 #pragma unroll
-            for (int e = 0; e < 8; e++)
-              if (!((m >> e) & 1)) v[e] = 0.f;
-          }
+          for (int e = 0; e < 8; e++)
+            if (!((m >> e) & 1)) v[e] = 0.f;
         } else if (p.gate) {
           const uint4 gg = *(const uint4*)((const bf16raw*)p.gate + grow * p.ldg + tn0 + c8e);
           const unsigned w[4] = {gg.x, gg.y, gg.z, gg.w};
@@ -336,12 +334,12 @@ bool pero_launch_gemm_w256(const GemmP& p0, long long batch, int k_split, bool t
     }                                                                                                                      \
     hipLaunchKernelGGL((gemm_bf16_w256<TA_, TB_, OF_, EP_>), grid, block, W_LDS_BYTES, st, p);                                  \
   } while (0)
-  const int epi = (p.flags & PERO_GEMM_ROWDOT) ? 2 : (p.flags & PERO_GEMM_COLSUM) ? 1 : (p.flags & PERO_GEMM_RELU_BITS) ? 3 : 0;
+  const int epi = (p.flags & PERO_GEMM_ROWDOT) ? 2 : (p.flags & PERO_GEMM_COLSUM) ? 1 : (p.flags & PERO_GEMM_RELU_BITS) ? ((p.flags & PERO_GEMM_RELU) ? 3 : 4) : 0;
   if (epi) {
     // the fused row dots exist for the K-contiguous bf16 products only; the column-sum mode (EPI 1) is not instantiated:
     // its per-tile atomics stall the persistent loop (see gemm.hip) - gemm_bf16_v256 takes those products
     if (ta || tb || out_f32 || epi == 1) return false;
-    if (epi == 2) LAUNCH_W(false, false, false, 2); else LAUNCH_W(false, false, false, 3);
+    if (epi == 2) LAUNCH_W(false, false, false, 2); else if (epi == 3) LAUNCH_W(false, false, false, 3); else LAUNCH_W(false, false, false, 4);
     return true;
   }
   if (!ta && !tb) { if (out_f32) LAUNCH_W(false, false, true, 0); else LAUNCH_W(false, false, false, 0); }

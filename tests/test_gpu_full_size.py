@@ -117,7 +117,7 @@ def test_config2_topk_error_counters_monotone(cfg2):
     assert c[0] == int(mask.sum()) and c[1] >= c[2] >= c[3] >= c[4] > 0
 
 
-@pytest.mark.parametrize("B,relu_bits", [(256, True), (512, False), (1024, False)])
+@pytest.mark.parametrize("B,relu_bits", [(256, False), (512, True), (1024, True)])
 def test_bench_scale_step_equals_the_weighted_sum_of_its_sub_batches(B, relu_bits, monkeypatch):
     """B = 256 / 512 / 1024 lines (1024 = bench.py's default; M = 65 536 ... 262 144 token rows: the persistent 256x256x64 products with every epilogue mode, the bit-mask ReLU
     gate, transposed-weight input gradients, long split-K weight gradients) against the SAME lines in 16-line sub-batches
@@ -126,7 +126,7 @@ def test_bench_scale_step_equals_the_weighted_sum_of_its_sub_batches(B, relu_bit
     import pero_pretraining_amd as P
     from pero_pretraining_amd import functional as F
     from pero_pretraining_amd.masked_pretraining import model as M
-    monkeypatch.setattr(F, "RELU_GATE_BITS", relu_bits)   # the optional bit-mask ReLU gate rides along at B = 256
+    monkeypatch.setattr(F, "RELU_GATE_BITS", relu_bits)   # both settings of the bit-mask ReLU gate (default: on)
     torch.manual_seed(1)
     model = M.MaskedTransformerEncoder(M.init_backbone(dict(CFG2_BB)), M.init_head(dict(CFG2_HD))).cuda().train()
     rng = np.random.default_rng(77)
