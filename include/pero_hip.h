@@ -56,8 +56,9 @@ extern "C" {
 
 const char* pero_last_error(void);
 int pero_abi_version(void);
-/* tuning knobs for benchmarking (A/B of kernel variants; defaults are the measured best): "gemm_policy" (0 = auto, 1..15 =
- * force one tile-kernel family, table in csrc/gemm.hip), "gemm_persistent" (1), "splitk_items" (512), "splitk_xcd" (1),
+/* tuning knobs for benchmarking (A/B of kernel variants; defaults are the measured best): "gemm_policy" (0 = auto, 1..16 =
+ * force one tile-kernel family, table in csrc/gemm.hip), "gemm_persistent" (1), "splitk_items" (512), "splitk_xcd" (1), "splitk_t256_min" (8: split-K weight
+ * gradients with at least that many 256x256 output tiles and a reduction of >= 131072 rows take the 256x256x64 kernel; 0 = never),
  * "splitk_nearest" (0).  Process-wide; not meant to be changed while products are in flight. */
 int pero_set_option(const char* name, int value);
 
