@@ -3,7 +3,7 @@
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pero_pretraining_amd import ops
-rows, d = 65536, 512
+rows, d = (int(sys.argv[1]) if len(sys.argv) > 1 else 65536), 512
 x = torch.randn(rows, d, device="cuda").bfloat16(); dy = torch.randn(rows, d, device="cuda").bfloat16()
 g = torch.ones(d, device="cuda"); b = torch.zeros(d, device="cuda")
 dg, db, dxs = torch.zeros(d, device="cuda"), torch.zeros(d, device="cuda"), torch.zeros(d, device="cuda")
