@@ -262,7 +262,8 @@ def backbone_fwd(mod, x, mask, offsets, dtype, save):
             xc = xc.float().contiguous()
         a0 = ops.patches_from_f32(xc, mask, tile, P, dtype, pitch)
     s = w // P
-    y0 = ops.gemm(a0[:, :kp], lowp.weight(mod.conv_layer.weight, dtype).view(d, -1), bias=mod.conv_layer.bias.detach())
+    y0 = ops.gemm(a0[:, :kp], lowp.weight(mod.conv_layer.weight, dtype).view(d, -1), bias=mod.conv_layer.bias.detach(),
+                  extra_flags=FWD_TILE_FLAGS)
     pe = mod.position_model.pe_table(x.device)
     t, mean0, rstd0 = ops.layernorm_fwd(y0, mod.intermediate_norm.weight.detach(), mod.intermediate_norm.bias.detach(),
                                         mod.intermediate_norm.eps, pe=pe, offsets=offsets, S=s)
