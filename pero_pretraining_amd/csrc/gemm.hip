@@ -377,8 +377,12 @@ static int g_splitk_nearest = 0;    // 1: k-slice count rounded to the nearest m
                                     // 48-tile in_proj gradient, 0.1 ms slower inside the step: tools/splitk_ab.py)
 static int g_gemm_persistent = 1;  // PERO_GEMM_TILE_V products: persistent w256 (epilogue under the next tile's first stage) instead of v256
 int g_pero_splitk_xcd = 1;  // one k-slice per XCD for split-K products (gemm_o.hip)
+extern int g_gemm_e_var;
+static int g_gemm_e256_min = 0;  // default policy: products with at least this many 256x256 tiles take the eight-phase kernel (0 = never)
 extern "C" int pero_set_option(const char* name, int value) {
   if (name && !strcmp(name, "gemm_policy")) { g_gemm_policy = value; return PERO_OK; }
+  if (name && !strcmp(name, "gemm_e_var")) { g_gemm_e_var = value; return PERO_OK; }
+  if (name && !strcmp(name, "gemm_e256_min")) { g_gemm_e256_min = value; return PERO_OK; }
   if (name && !strcmp(name, "splitk_xcd")) { g_pero_splitk_xcd = value; return PERO_OK; }
   if (name && !strcmp(name, "splitk_nearest")) { g_splitk_nearest = value; return PERO_OK; }
   if (name && !strcmp(name, "splitk_t256_min")) { g_splitk_t256_min = value; return PERO_OK; }
@@ -461,7 +465,7 @@ static int gemm_dispatch(const void* A, const void* B, void* C, const float* bia
     // them exactly under these conditions
     PERO_REQUIRE(fast && gate && batch == 1 && out_dtype == PERO_BF16 && !ta && !(flags & PERO_GEMM_ATOMIC) && !forced0 && M % 256 == 0 &&
                  N % 128 == 0 && K % 32 == 0 && !(flags & PERO_GEMM_ROWDOT) &&
-                 (g_gemm_policy == 0 || g_gemm_policy == 7 || g_gemm_policy == 10 || g_gemm_policy == 11 || g_gemm_policy == 12),
+                 (g_gemm_policy == 0 || g_gemm_policy == 7 || g_gemm_policy == 10 || g_gemm_policy == 11 || g_gemm_policy == 12 || g_gemm_policy == 20),
                  "pero_gemm: PERO_GEMM_RELU_BITS needs a bf16 product for the 256-row tile kernels (M %% 256, N %% 128, K %% 32, batch 1)");
   }
   if (fast) {
@@ -530,6 +534,14 @@ static int gemm_dispatch(const void* A, const void* B, void* C, const float* bia
       PERO_CHECK_LAUNCH("pero_gemm(bf16 p128)");
       return PERO_OK;
     }
+    // the eight-phase persistent 256x256x64 kernel (gemm_e.hip): stored bf16 products with every fused epilogue
+    if ((g_gemm_policy == 20 || (g_gemm_policy == 0 && g_gemm_e256_min > 0 && t256 >= g_gemm_e256_min)) && !forced0 && !atomic &&
+        pero_launch_gemm_e256(pc, batch, k_split, ta, tb, out_dtype == PERO_F32, st, -1)) {
+      *colsum_fused = want_cs;
+      PERO_CHECK_LAUNCH("pero_gemm(e256)");
+      return PERO_OK;
+    }
+    PERO_REQUIRE(!(g_gemm_policy == 20 && (g_gemm_e_var & 8)), "pero_gemm: the stamp build did not take this product");  // its `gate` is a debug buffer
     if (g_gemm_policy == 15 && !forced0 && !atomic && !want_cs && pero_launch_gemm_x256(p, batch, k_split, ta, tb, out_dtype == PERO_F32, st)) {
       PERO_CHECK_LAUNCH("pero_gemm(x256)");
       return PERO_OK;

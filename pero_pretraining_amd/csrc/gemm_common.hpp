@@ -44,3 +44,5 @@ bool pero_launch_gemm_x256(const GemmP& p, long long batch, int k_split, bool ta
 bool pero_launch_gemm_w256(const GemmP& p, long long batch, int k_split, bool ta, bool tb, bool out_f32, hipStream_t st);
 // host entry of the software-pipelined 128x128x32 kernel (gemm_p.hip)
 bool pero_launch_gemm_p128(const GemmP& p, long long batch, int k_split, bool ta, bool tb, bool out_f32, hipStream_t st);
+// host entry of the eight-phase ping-pong persistent 256x256x64 kernel (gemm_e.hip)
+bool pero_launch_gemm_e256(const GemmP& p, long long batch, int k_split, bool ta, bool tb, bool out_f32, hipStream_t st, int var = 0);

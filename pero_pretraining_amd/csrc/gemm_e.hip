@@ -1,0 +1,562 @@
+// PERSISTENT 256 x 256 x 64 bf16 tile GEMM on the EIGHT-PHASE PING-PONG schedule (cdna_hip_programming.md section 5, "The 256^2
+// 8-phase template"): eight waves as 2 (M) x 4 (N), 128 x 64 outputs per wave, one workgroup per CU.
+//
+//  * A K-tile (256 x 64 of A, 256 x 64 of B) lives in LDS as FOUR half tiles of 16 KiB (A0, A1, B0, B1 = 128 rows x 64 k);
+//    a wave owns 64 rows of each A half and 32 columns of each B half, i.e. its 128 x 64 outputs are 2 x 2 blocks of
+//    64 x 32 = (A half) x (B half).  One PHASE = one block x K = 64 = 16 MFMAs; four phases per K-tile:
+//        P1: read B0 (4 ds_read_b128), A0 (8)  -> A0 x B0        P3: read A1 (8) -> A1 x B1
+//        P2: read B1 (4)                       -> A0 x B1        P4: (nothing)   -> A1 x B0
+//    so a half tile is read exactly once per wave and at most 64 fragment registers are live beside the 128 accumulators.
+//  * Every phase is  { fragment reads ; LDS-DMA of ONE half tile (2 x global_load_lds_dwordx4) ; s_barrier ; lgkmcnt(0) ;
+//    s_setprio 1 ; 16 MFMA ; s_setprio 0 ; s_barrier }.  Waves 4-7 take one extra barrier before the loop: the two waves of
+//    a SIMD run half a phase apart, one in its MFMA cluster while the other reads / stages (the ping-pong).
+//  * The LDS-DMA stream is ONE sequence over (tile, K-tile) pairs, three half tiles ahead of the reads, never drained:
+//    a counted s_waitcnt vmcnt once per K-tile (phase 4), raw s_barrier, lgkmcnt only.  Issue order B0(t+2) [P2], A0(t+2)
+//    [P3], B1(t+2) [P4], A1(t+2) [P1 of t+1]: a slot is restaged two phases after its last read (B0: one phase, its reads are
+//    retired by the lgkmcnt(8) in front of P1's first barrier); the wait in P4 of K-tile t retires everything up to
+//    A1(t+1), read from P1 of t+1 on (one phase after the wait: staggered waves need the extra barrier).
+//  * Persistent: one workgroup per CU walks tiles bid, bid + G, ...; the next tile's first K-tiles are part of the same
+//    stream, so the pipeline never refills.  vmcnt is ONE in-order counter for LDS-DMA, loads and stores: the last
+//    half tile the next tile needs before its second K-tile (A1 of K-tile 1) is issued AHEAD of the epilogue's stores, and
+//    the first K-tile's wait counts them out - the stores then have two K-tiles of main loop to drain.
+//  * Epilogue straight from the accumulators (no LDS, no barrier): operands are swapped in the MFMA so that a lane owns 4
+//    consecutive output columns of one row; v_permlane16_swap between the two 16 x 16 tiles of a 32-column block gives it 8
+//    consecutive columns -> one 16-byte store (64 contiguous bytes per row and instruction).  The bias is the accumulators'
+//    INITIAL value (a per-wave 1 KiB copy of the tile's bias row, fetched by one more LDS-DMA of the same stream: an
+//    ordinary load would have to wait for every LDS-DMA issued before it).  Side inputs (residual rows, the second matrix
+//    of the row dots, the ReLU bit mask) are fetched by inline-asm buffer loads the compiler does not count: half of them
+//    in phase 4 of the tile's last K-tile, half at the start of the epilogue, each waited for by a counted vmcnt.
+#include "gemm_common.hpp"
+#include <type_traits>
+
+#define E_BM 256
+#define E_BN 256
+#define E_BK 64
+#define E_HALF 16384               // half tile: 128 rows x 64 k (bf16)
+#define E_KTILE (4 * E_HALF)       // A0 A1 B0 B1
+#define E_RING (2 * E_KTILE)       // 128 KiB: two K-tiles
+#define E_BIAS E_RING              // 8 x 1 KiB: each wave's copy of the tile's 256 bias floats
+#define E_LDS_BYTES (E_RING + 8192)
+
+// epilogue modes
+#define EP_PLAIN 0       // bias
+#define EP_RELU 1        // bias, ReLU
+#define EP_RESID 2       // bias, + residual (bf16 rows of C's shape)
+#define EP_RELU_BITS 3   // bias, ReLU, `gate` receives the bit mask (stored C > 0)
+#define EP_GATE_BITS 4   // `gate` bit mask applied; with PERO_GEMM_COLSUM the column sums of the stored result are added to `bias`
+#define EP_ROWDOT 6      // `bias`[m][n / 128] += row dots of the stored result with `gate` (bf16 rows of C's shape)
+
+typedef int ei4v __attribute__((ext_vector_type(4)));
+typedef unsigned eu4v __attribute__((ext_vector_type(4)));
+typedef unsigned eu2v __attribute__((ext_vector_type(2)));
+
+// per-thread byte offset of its two LDS-DMA pieces inside a half tile's source (constant over the whole kernel).
+// Rows of the half tiles are INTERLEAVED so that a wave's outputs are contiguous in memory: row r of A half h is row
+// (r >> 6) * 128 + 64 h + (r & 63) of the tile, row r of B half h is column (r >> 5) * 64 + 32 h + (r & 31).
+template <bool TR, bool ISA>
+__device__ __forceinline__ unsigned elane_off(long long ld, int tid) {
+  if (!TR) {  // K-contiguous operand: piece = 8 rows x 128 B; LDS slot (tid & 7) of row r holds chunk slot ^ (r & 7)
+    const int r = tid >> 3, chunk = (tid & 7) ^ (r & 7);
+    const int g = ISA ? r : ((r >> 5) * 64 + (r & 31));
+    return (unsigned)((g * ld + chunk * 8) * 2);
+  } else {    // K-major operand: piece = 4 k-rows x 256 B; 32-byte blocks of a k-row XORed with fk(krow)
+    const int krow = tid >> 4, slot = tid & 15;
+    const int c = ((((slot >> 1) ^ fk(krow)) << 1) | (slot & 1)) * 8;
+    const int g = ISA ? ((c >> 6) * 128 + (c & 63)) : ((c >> 5) * 64 + (c & 31));
+    return (unsigned)((krow * ld + g) * 2);
+  }
+}
+// byte steps of an operand's half-tile stream (uniform): tile origin t0, K-tile u, half h, second piece
+template <bool TR, int HS>
+struct EStep {
+  long long tile, ktile, half, piece;
+  __device__ __forceinline__ EStep(long long ld) {
+    if (!TR) { tile = ld * 2; ktile = E_BK * 2; half = HS * ld * 2; piece = 128 * ld * 2; }
+    else { tile = 2; ktile = E_BK * ld * 2; half = HS * 2; piece = 32 * ld * 2; }
+  }
+};
+__device__ __forceinline__ void eglds2(const unsigned char* base, long long piece, unsigned off, unsigned char* dst) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off),
+                                   (__attribute__((address_space(3))) void*)(dst), 16, 0, 0);
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + piece + off),
+                                   (__attribute__((address_space(3))) void*)(dst + 8192), 16, 0, 0);
+}
+// buffer descriptor from uniform values (raw buffer, 32-bit offsets, no bounds beyond `bytes`)
+__device__ __forceinline__ ei4v ersrc(const void* base, unsigned bytes) {
+  const unsigned long long b = (unsigned long long)base;
+  ei4v r;
+  r[0] = (int)(unsigned)b; r[1] = (int)(unsigned)((b >> 32) & 0xffffu); r[2] = (int)bytes; r[3] = 0x00020000;
+  return r;
+}
+// loads the compiler does not see (no wait of its own, not in its vmcnt bookkeeping): waited for by E_WAIT* below
+#define E_BLOAD16(dst_, voff_, rs_, soff_, imm_) \
+  asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4" : "=v"(dst_) : "v"(voff_), "s"(rs_), "s"(soff_), "i"(imm_) : "memory")
+#define E_BLOAD8(dst_, voff_, rs_, soff_, imm_) \
+  asm volatile("s_nop 4\n\tbuffer_load_dwordx2 %0, %1, %2, %3 offen offset:%4" : "=v"(dst_) : "v"(voff_), "s"(rs_), "s"(soff_), "i"(imm_) : "memory")
+#define E_WAIT8(n_, r_) \
+  asm volatile("s_waitcnt vmcnt(%8)" : "+v"(r_[0]), "+v"(r_[1]), "+v"(r_[2]), "+v"(r_[3]), "+v"(r_[4]), "+v"(r_[5]), "+v"(r_[6]), "+v"(r_[7]) : "i"(n_) : "memory")
+#define E_WAIT4(n_, r_) \
+  asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r_[0]), "+v"(r_[1]), "+v"(r_[2]), "+v"(r_[3]) : "i"(n_) : "memory")
+
+template <int EPI> struct ECnt {
+  // vector-memory operations of the epilogue, in issue order: side loads of rows 0-63 (phase 4 of the last K-tile), [A1 of the
+  // next tile's K-tile 1], side loads of rows 64-127, then the stores / atomics of the two halves
+  static constexpr int L0 = (EPI == EP_RESID || EPI == EP_ROWDOT) ? 8 : (EPI == EP_GATE_BITS ? 4 : 0);
+  static constexpr int L1 = L0;
+  static constexpr int S_HALF = 8 + (EPI == EP_RELU_BITS ? 4 : 0) + (EPI == EP_ROWDOT ? 4 : 0);
+};
+
+template <bool TA, bool TB, int EPI, int VAR>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  typedef ECnt<EPI> CN;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int ntn = (int)(p.N / E_BN);
+  const int nt = (int)(p.M / E_BM) * ntn;
+  const int G = gridDim.x;  // multiple of 8
+  const int q8 = nt >> 3, r8 = nt & 7;
+  const bf16raw* A = (const bf16raw*)p.A;
+  const bf16raw* B = (const bf16raw*)p.B;
+  const int nk = (int)(p.K / E_BK);  // >= 2 (launcher)
+  const unsigned offA = elane_off<TA, true>(p.lda, tid), offB = elane_off<TB, false>(p.ldb, tid);
+  const bool colsum = EPI == EP_GATE_BITS && (p.flags & PERO_GEMM_COLSUM);
+
+  auto tile_of = [&](int T, long long& tm0, long long& tn0) {
+    const int xcd = T & 7, loc = T >> 3;
+    const int id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
+    tm0 = (long long)(id / ntn) * E_BM;
+    tn0 = (long long)(id % ntn) * E_BN;
+  };
+  int T = blockIdx.x;
+  if (T >= nt) return;
+  long long tm0, tn0, nm0, nn0;
+  tile_of(T, tm0, tn0);
+  bool has_next = T + G < nt;
+  tile_of(has_next ? T + G : T, nm0, nn0);
+
+  // fragment read addresses (per lane, relative to a half tile's base)
+  //  K-contiguous image [128 rows][128 B]: row = row0 + (lane & 15), 16-byte chunk (4 s + (lane >> 4)) ^ (row & 7)
+  const unsigned rc0 = (unsigned)((lane & 15) * 128 + ((((lane >> 4)) ^ (lane & 7)) << 4));  // s = 0; s = 1 is rc0 ^ 64
+  //  K-major image [64 k-rows][256 B]: see frag_kmajor (gemm.hip); 32-byte block (col >> 4) ^ fk(krow)
+  const int li = lane & 15, lq = lane >> 4;
+  const int kf = (li >> 2) | ((lq & 1) << 2);
+  const unsigned rk0 = (unsigned)((8 * lq + (li >> 2)) * 256 + 8 * (li & 3));
+  auto rdA = [&](const unsigned char* base, int i, int s) -> bf8v {  // rows 64 wr + 16 i of an A half
+    if (!TA) return *(const bf8v*)(base + (64 * wr + 16 * i) * 128 + (rc0 ^ (s << 6)));
+    const unsigned char* a = base + rk0 + s * 32 * 256 + (((4 * wr + i) ^ kf) << 5);
+    return lds_tr16_pair(a, a + 4 * 256);
+  };
+  auto rdB = [&](const unsigned char* base, int j, int s) -> bf8v {  // rows 32 wc + 16 j of a B half
+    if (!TB) return *(const bf8v*)(base + (32 * wc + 16 * j) * 128 + (rc0 ^ (s << 6)));
+    const unsigned char* a = base + rk0 + s * 32 * 256 + (((2 * wc + j) ^ kf) << 5);
+    return lds_tr16_pair(a, a + 4 * 256);
+  };
+
+  f4v acc[2][2][4][2];  // [A half][B half][i][j]
+  bf8v fa[4][2], fb0[2][2], fb1[2][2];
+
+#define E_RD_A(H_)                                                            \
+  _Pragma("unroll") for (int i_ = 0; i_ < 4; i_++) {                          \
+    fa[i_][0] = rdA(kt + (H_) * E_HALF, i_, 0);                               \
+    fa[i_][1] = rdA(kt + (H_) * E_HALF, i_, 1);                               \
+  }
+#define E_RD_B(F_, H_)                                                        \
+  _Pragma("unroll") for (int j_ = 0; j_ < 2; j_++) {                          \
+    F_[j_][0] = rdB(kt + (2 + (H_)) * E_HALF, j_, 0);                         \
+    F_[j_][1] = rdB(kt + (2 + (H_)) * E_HALF, j_, 1);                         \
+  }
+#define E_MFMA(HA_, HB_, F_)                                                                                              \
+  __builtin_amdgcn_s_setprio(1);                                                                                          \
+  _Pragma("unroll") for (int s_ = 0; s_ < 2; s_++)                                                                        \
+  _Pragma("unroll") for (int i_ = 0; i_ < 4; i_++)                                                                        \
+  _Pragma("unroll") for (int j_ = 0; j_ < 2; j_++)                                                                        \
+    acc[HA_][HB_][i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F_[j_][s_], fa[i_][s_], acc[HA_][HB_][i_][j_], 0, 0, 0); \
+  __builtin_amdgcn_s_setprio(0);
+#define E_BAR()                                  \
+  __builtin_amdgcn_sched_barrier(0);             \
+  __builtin_amdgcn_s_barrier();                  \
+  __builtin_amdgcn_sched_barrier(0);
+#define E_LGKM0()                                          \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       \
+  __builtin_amdgcn_sched_barrier(0);
+
+  // the LDS-DMA stream: half tile `which` (0 A0, 1 A1, 2 B0, 3 B1) of K-tile u of the current tile (u >= nk: of the next
+  // one; a workgroup's last tile "prefetches" its own first K-tiles again: the stream keeps its shape, no branches)
+  const EStep<TA, 64> sa(p.lda);
+  const EStep<TB, 32> sb(p.ldb);
+  const unsigned char* cA = (const unsigned char*)A + tm0 * sa.tile;
+  const unsigned char* cB = (const unsigned char*)B + tn0 * sb.tile;
+  const unsigned char* nA = (const unsigned char*)A + nm0 * sa.tile;
+  const unsigned char* nB = (const unsigned char*)B + nn0 * sb.tile;
+  auto issue = [&](int u, int which, unsigned char* ktbase) {
+    const bool nx = u >= nk;
+    const long long uu = nx ? u - nk : u;
+    unsigned char* dst = ktbase + which * E_HALF + wave * 1024;
+    if (which < 2) eglds2((nx ? nA : cA) + uu * sa.ktile + which * sa.half, sa.piece, offA, dst);
+    else eglds2((nx ? nB : cB) + uu * sb.ktile + (which - 2) * sb.half, sb.piece, offB, dst);
+  };
+  const bool use_bias = (EPI <= EP_RELU_BITS) && p.bias;
+  unsigned char* const biasl = smem + E_BIAS + wave * 1024;
+  auto issue_bias = [&](long long bn) {  // 256 floats = 64 lanes x 16 B, this wave's private copy
+    const float* src = use_bias ? p.bias + bn : (const float*)p.B;  // (no bias: any readable address; the copy is not used)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const unsigned char*)src + lane * 16),
+                                     (__attribute__((address_space(3))) void*)(biasl), 16, 0, 0);
+  };
+
+  if (VAR & 2) {
+    // de-phase the workgroups: all tiles take the same time, so without this every CU reaches its epilogue (128 KiB of
+    // stores) at the same moment.  Workgroups that stream the same A panel (ntn consecutive ones of an XCD) stay together.
+    const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3, per = (G >> 3);
+    const int ngr = (per + ntn - 1) / ntn, gr = loc / ntn;
+    const int period = nk * 2900 + 6000;                       // cycles per tile, roughly
+    const int delay = (int)((long long)period * (gr * 8 + xcd) / (ngr * 8));
+    for (int i = 0; i < delay; i += 1024) __builtin_amdgcn_s_sleep(16);
+  }
+  // ---- prologue: K-tile 0 and all of K-tile 1 (a tile's A1(1) is always issued ahead of its first K-tile)
+  issue_bias(tn0);
+  issue(0, 2, smem); issue(0, 0, smem); issue(0, 3, smem); issue(0, 1, smem);
+  issue(1, 2, smem + E_KTILE); issue(1, 0, smem + E_KTILE); issue(1, 3, smem + E_KTILE); issue(1, 1, smem + E_KTILE);
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  E_BAR();
+  if (wr == 1) { E_BAR(); }  // the stagger: waves 4-7 run one barrier behind
+
+  int d = 0;  // ring slot of the current K-tile
+  bool first = true;
+  // VAR 8 (diagnostic build): s_memtime stamps of waves 0 and 4 per tile -> p.gate as u64 [G][2][64 tiles][4]
+  unsigned long long* stamp = nullptr;
+  int tix = 0;
+  if (VAR & 8) stamp = (unsigned long long*)p.gate + ((size_t)blockIdx.x * 2 + wr) * 64 * 4;
+#define E_STAMP(k_) if ((VAR & 8) && wc == 0 && lane == 0 && tix < 64) stamp[tix * 4 + (k_)] = (k_) == 3 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime();
+
+  // epilogue addressing: after the column swap a lane holds columns c8 .. c8 + 7 of a 32-column block of row li
+  const int cq = ((lq & 1) << 1) | (lq >> 1), c8 = 8 * cq;
+  const unsigned cvo = (unsigned)(((128 * wr + li) * p.ldc + 64 * wc + c8) * 2);   // C
+  const unsigned gvo = (unsigned)(((128 * wr + li) * (EPI == EP_RESID ? p.ldr : p.ldg) + 64 * wc + c8) * 2);  // residual / row-dot matrix
+  const unsigned mvo = (unsigned)((128 * wr + li) * p.ldg + 8 * wc);               // bit mask: 8 bytes per row and wave
+  eu4v side0[8], side1[8];   // side inputs of rows 0-63 / 64-127 (EP_RESID, EP_ROWDOT: 16 B per unit)
+  eu2v sm0[4], sm1[4];       // EP_GATE_BITS: the 8 mask bytes of a row (this wave's 64 columns), per row group
+
+  for (;;) {
+    E_STAMP(0);
+    E_STAMP(3);
+    // accumulators start at the bias (or zero): lane owns columns 64 wc + 32 hb + 16 j + 4 (lane >> 4) .. + 3
+#pragma unroll
+    for (int hb = 0; hb < 2; hb++)
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        f4v b4 = (f4v){0.f, 0.f, 0.f, 0.f};
+        if (use_bias) b4 = *(const f4v*)(biasl + (64 * wc + 32 * hb + 16 * j + 4 * lq) * 4);
+#pragma unroll
+        for (int ha = 0; ha < 2; ha++)
+#pragma unroll
+          for (int i = 0; i < 4; i++) acc[ha][hb][i][j] = b4;
+      }
+    E_LGKM0();
+    issue_bias(nn0);  // next tile's bias row: part of the stream (older than everything a later wait counts)
+
+    // side-input descriptor of this tile
+    const int spitch = (int)(EPI == EP_RESID ? p.ldr * 2 : EPI == EP_ROWDOT ? p.ldg * 2 : p.ldg);  // bytes per row
+    const ei4v srs = ersrc(EPI == EP_RESID ? (const void*)((const bf16raw*)p.resid + tm0 * p.ldr + tn0)
+                           : EPI == EP_ROWDOT ? (const void*)((const bf16raw*)p.gate + tm0 * p.ldg + tn0)
+                           : (const void*)((const unsigned char*)p.gate + tm0 * p.ldg + (tn0 >> 3)),
+                           (unsigned)(256 * spitch));
+
+    // one K-tile; LAST = the tile's last one (peeled: the side loads of the epilogue start in its phase 4 and their registers
+    // are live from there only)
+    auto ktile = [&](auto last_c, const int t) __attribute__((always_inline)) {
+      constexpr bool last = decltype(last_c)::value;
+      unsigned char* const kt = smem + d * E_KTILE;         // K-tile t
+      unsigned char* const kn = smem + (d ^ 1) * E_KTILE;   // K-tiles t + 1 (being completed) and, slot by slot, t + 2
+      // P1
+      E_RD_B(fb0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      E_RD_A(0);
+      if (last || t > 0) issue(t + 1, 1, kn);                       // A1(t+1)  (a tile's A1(1) went out ahead of the previous epilogue)
+      if (TA) asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");  // the B0 reads (issued first) are done: B0 may be restaged in P2
+      else asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+      E_BAR();
+      E_LGKM0();
+      E_MFMA(0, 0, fb0);
+      E_BAR();
+      // P2
+      E_RD_B(fb1, 1);
+      issue(t + 2, 2, kt);                                  // B0(t+2)
+      E_BAR();
+      E_LGKM0();
+      E_MFMA(0, 1, fb1);
+      E_BAR();
+      // P3
+      E_RD_A(1);
+      issue(t + 2, 0, kt);                                  // A0(t+2)
+      E_BAR();
+      E_LGKM0();
+      E_MFMA(1, 1, fb1);
+      E_BAR();
+      // P4
+      if (CN::L0 && last) {  // side inputs of the wave's rows 0-63
+        if (EPI == EP_GATE_BITS) {
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const int so = 16 * i * spitch;
+            E_BLOAD8(sm0[i], mvo, srs, so, 0);
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const int so = 16 * i * spitch;
+            E_BLOAD16(side0[2 * i], gvo, srs, so, 0);
+            E_BLOAD16(side0[2 * i + 1], gvo, srs, so, 64);
+          }
+        }
+      }
+      issue(t + 2, 3, kt);                                  // B1(t+2)
+      // K-tile t+1 has landed (this wave's pieces).  What was issued after its last half tile A1(t+1) stays in flight:
+      // normally the three half tiles of t+2; in a tile's first K-tile also the previous epilogue (side loads of rows 64-127,
+      // stores) and the bias row; in its last K-tile the side loads issued just above.
+      if (!last && t == 0 && !first && colsum) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(6 + 1 + CN::L1 + 2 * CN::S_HALF + 16) : "memory");  // + the 16 column-sum atomics
+      else if (!last && t == 0 && !first) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(6 + 1 + CN::L1 + 2 * CN::S_HALF) : "memory");
+      else if (CN::L0 && last) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(6 + CN::L0) : "memory");
+      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      E_BAR();
+      E_MFMA(1, 0, fb0);
+      E_BAR();
+      d ^= 1;
+    };
+    for (int t = 0; t < nk - 1; t++) ktile(std::false_type{}, t);
+    ktile(std::true_type{}, nk - 1);
+
+    // ---- epilogue, straight from the accumulators
+    E_STAMP(1);
+    first = false;
+    issue(nk + 1, 1, smem + (d ^ 1) * E_KTILE);  // A1 of the next tile's K-tile 1: ahead of the stores in the in-order counter
+    {
+      const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc((bf16raw*)p.C + tm0 * p.ldc + tn0, 0, (int)(256 * p.ldc * 2), 0x00020000);
+      const int cpitch = (int)(p.ldc * 2);
+      float cs[2][8];  // EP_GATE_BITS + column sums
+      float rd[4];     // EP_ROWDOT: row dots of one row group
+#pragma unroll
+      for (int hb = 0; hb < 2; hb++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) cs[hb][e] = 0.f;
+#pragma unroll
+      for (int ha = 0; ha < 2; ha++) {
+        if (CN::L1 && ha == 0) {  // side inputs of rows 64-127, then wait for those of rows 0-63
+          if (EPI == EP_GATE_BITS) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+              const int so = (64 + 16 * i) * spitch;
+              E_BLOAD8(sm1[i], mvo, srs, so, 0);
+            }
+            E_WAIT4(2 + 2 + CN::L1, sm0);
+          } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+              const int so = (64 + 16 * i) * spitch;
+              E_BLOAD16(side1[2 * i], gvo, srs, so, 0);
+              E_BLOAD16(side1[2 * i + 1], gvo, srs, so, 64);
+            }
+            E_WAIT8(2 + 2 + CN::L1, side0);
+          }
+        }
+        if (CN::L1 && ha == 1) {
+          if (EPI == EP_GATE_BITS) E_WAIT4(CN::S_HALF, sm1);
+          else E_WAIT8(CN::S_HALF, side1);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const int so = (64 * ha + 16 * i) * cpitch;
+          unsigned mL = 0, mH = 0;
+          if (EPI == EP_ROWDOT) rd[i] = 0.f;
+#pragma unroll
+          for (int hb = 0; hb < 2; hb++) {
+            const f4v x = acc[ha][hb][i][0], y = acc[ha][hb][i][1];
+            eu4v o;
+            if (EPI == EP_RESID) {
+              // f32 columns first (one rounding): even lane groups keep x and take the odd neighbour's x, odd ones y
+              float v[8];
+#pragma unroll
+              for (int e = 0; e < 4; e++) {
+                auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(x[e]), __float_as_uint(y[e]), false, false);
+                v[e] = __uint_as_float(sw[0]); v[4 + e] = __uint_as_float(sw[1]);
+              }
+              const eu4v r4 = ha ? side1[2 * i + hb] : side0[2 * i + hb];
+#pragma unroll
+              for (int e = 0; e < 4; e++) { v[2 * e] += __uint_as_float(r4[e] << 16); v[2 * e + 1] += __uint_as_float(r4[e] & 0xffff0000u); }
+              o[0] = pack2bf(v[0], v[1]); o[1] = pack2bf(v[2], v[3]); o[2] = pack2bf(v[4], v[5]); o[3] = pack2bf(v[6], v[7]);
+            } else {
+              float xs[4] = {x[0], x[1], x[2], x[3]}, ys[4] = {y[0], y[1], y[2], y[3]};
+              if (EPI == EP_RELU || EPI == EP_RELU_BITS) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) { xs[e] = fmaxf(xs[e], 0.f); ys[e] = fmaxf(ys[e], 0.f); }
+              }
+              const unsigned px0 = pack2bf(xs[0], xs[1]), px1 = pack2bf(xs[2], xs[3]);
+              const unsigned py0 = pack2bf(ys[0], ys[1]), py1 = pack2bf(ys[2], ys[3]);
+              auto s0 = __builtin_amdgcn_permlane16_swap(px0, py0, false, false);
+              auto s1 = __builtin_amdgcn_permlane16_swap(px1, py1, false, false);
+              o[0] = s0[0]; o[1] = s1[0]; o[2] = s0[1]; o[3] = s1[1];
+            }
+            if (EPI == EP_RELU_BITS) {
+              // bit e = (stored column e > 0); after the ReLU every half word is +0, -0 or positive
+              unsigned z = 0;
+#pragma unroll
+              for (int k = 0; k < 4; k++) {
+                const unsigned m = (((o[k] & 0x7fff7fffu) + 0x7fff7fffu) & 0x80008000u) >> 15;  // bit 0: low half > 0, bit 16: high half
+                z |= m << (2 * k);
+              }
+              const unsigned byte = (z & 0x55u) | ((z >> 15) & 0xaau);
+              if (hb == 0) mL = byte << (8 * cq); else mH = byte << (8 * cq);
+            }
+            if (EPI == EP_GATE_BITS) {
+              const eu2v mm = ha ? sm1[i] : sm0[i];
+              const unsigned byte = ((hb ? mm[1] : mm[0]) >> (8 * cq)) & 0xffu;
+#pragma unroll
+              for (int k = 0; k < 4; k++) {
+                const unsigned keep = (((byte >> (2 * k)) & 1u) ? 0x0000ffffu : 0u) | (((byte >> (2 * k + 1)) & 1u) ? 0xffff0000u : 0u);
+                o[k] &= keep;
+                if (colsum) { cs[hb][2 * k] += __uint_as_float(o[k] << 16); cs[hb][2 * k + 1] += __uint_as_float(o[k] & 0xffff0000u); }
+              }
+            }
+            if (EPI == EP_ROWDOT) {
+              const eu4v g4 = ha ? side1[2 * i + hb] : side0[2 * i + hb];
+#pragma unroll
+              for (int k = 0; k < 4; k++) {
+                rd[i] += __uint_as_float(o[k] << 16) * __uint_as_float(g4[k] << 16);
+                rd[i] += __uint_as_float(o[k] & 0xffff0000u) * __uint_as_float(g4[k] & 0xffff0000u);
+              }
+            }
+            if (VAR & 4) {  // ablation: no stores (the values stay live)
+              asm volatile("" :: "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]));
+              if (i + hb == 0) __builtin_amdgcn_raw_buffer_store_b128(o, crs, cvo + 64 * hb, so, 0);
+            } else {
+              __builtin_amdgcn_raw_buffer_store_b128(o, crs, cvo + 64 * hb, so, (VAR & 16) ? 16 : (VAR & 32) ? 2 : 0);
+            }
+          }
+          if (EPI == EP_RELU_BITS) {
+            // OR over the four lanes of a row (lane, lane ^ 16, lane ^ 32, lane ^ 48): every one of them then holds the row's 8 bytes
+            auto a = __builtin_amdgcn_permlane32_swap(mL, mL, false, false); mL = a[0] | a[1];
+            auto b = __builtin_amdgcn_permlane32_swap(mH, mH, false, false); mH = b[0] | b[1];
+            auto c = __builtin_amdgcn_permlane16_swap(mL, mL, false, false); mL = c[0] | c[1];
+            auto e2 = __builtin_amdgcn_permlane16_swap(mH, mH, false, false); mH = e2[0] | e2[1];
+            const eu2v mo = {mL, mH};
+            const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc((unsigned char*)p.gate + tm0 * p.ldg + (tn0 >> 3), 0, (int)(256 * p.ldg), 0x00020000);
+            // all four store them (same address, same data): one instruction, no branch
+            __builtin_amdgcn_raw_buffer_store_b64(mo, mrs, mvo, (64 * ha + 16 * i) * (int)p.ldg, 0);
+          }
+          if (EPI == EP_ROWDOT) {
+            // sum over the four lanes of a row, then lane group 0 adds into [m][n / 128] (two waves per 128-column block)
+            float s = rd[i];
+            auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+            s = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+            auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+            s = __uint_as_float(b[0]) + __uint_as_float(b[1]);
+            float* dst = (float*)p.bias + (tm0 + 128 * wr + 64 * ha + 16 * i + li) * (p.N >> 7) + ((tn0 + 64 * wc) >> 7);
+            if (lq == 0) atomicAdd(dst, s);
+          }
+        }
+      }
+      if (colsum) {
+        // column sums of the tile's 128 rows of this wave: over the 16 rows of a lane group by shuffles, then one atomic per column
+#pragma unroll
+        for (int hb = 0; hb < 2; hb++)
+#pragma unroll
+          for (int e = 0; e < 8; e++) {
+            float s = cs[hb][e];
+            s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
+            cs[hb][e] = s;
+          }
+        if (li == 0) {
+#pragma unroll
+          for (int hb = 0; hb < 2; hb++)
+#pragma unroll
+            for (int e = 0; e < 8; e++) atomicAdd((float*)p.bias + tn0 + 64 * wc + 32 * hb + c8 + e, cs[hb][e]);
+        }
+      }
+    }
+    E_STAMP(2);
+    tix++;
+    if (!has_next) break;
+    T += G;
+    tm0 = nm0; tn0 = nn0; cA = nA; cB = nB;
+    has_next = T + G < nt;
+    tile_of(has_next ? T + G : T, nm0, nn0);
+    nA = (const unsigned char*)A + nm0 * sa.tile;
+    nB = (const unsigned char*)B + nn0 * sb.tile;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last tile's surplus prefetches land before the LDS is released
+  if (wr == 0) { E_BAR(); }  // balance the stagger barrier
+#undef E_RD_A
+#undef E_RD_B
+#undef E_MFMA
+#undef E_BAR
+#undef E_LGKM0
+#undef E_STAMP
+}
+
+// Qualifies: one problem (batch 1), no split-K, bf16 stored output, alpha == 1, M % 256 == N % 256 == K % 64 == 0, K >= 128.
+int g_gemm_e_var = 0;
+bool pero_launch_gemm_e256(const GemmP& p0, long long batch, int k_split, bool ta, bool tb, bool out_f32, hipStream_t st, int var) {
+  if (p0.M % E_BM || p0.N % E_BN || p0.K % E_BK || p0.K < 2 * E_BK || batch != 1 || k_split > 1 || out_f32) return false;
+  if (p0.flags & (PERO_GEMM_ATOMIC | PERO_GEMM_ACCUM)) return false;
+  if (var < 0) var = g_gemm_e_var;
+  if (p0.alpha != 1.0f) return false;
+  if (p0.lda >= (1LL << 22) || p0.ldb >= (1LL << 22) || p0.ldc >= (1LL << 22)) return false;  // 32-bit byte offsets inside a tile
+  const bool relu = p0.flags & PERO_GEMM_RELU, bits = p0.flags & PERO_GEMM_RELU_BITS, rowdot = p0.flags & PERO_GEMM_ROWDOT,
+             cs = p0.flags & PERO_GEMM_COLSUM;
+  int epi;
+  if (var & 8) epi = EP_PLAIN;                       // stamp build: `gate` is the stamp buffer
+  else if (rowdot) { if (relu || bits || cs || p0.resid || !p0.gate || !p0.bias) return false; epi = EP_ROWDOT; }
+  else if (bits) { if (!p0.gate || p0.resid || (relu && cs)) return false; epi = relu ? EP_RELU_BITS : EP_GATE_BITS; }
+  else if (cs || p0.gate) return false;              // column sums without the bit mask, bf16 gate rows: other kernels
+  else if (p0.resid) { if (relu) return false; epi = EP_RESID; }
+  else epi = relu ? EP_RELU : EP_PLAIN;
+  if ((epi == EP_RESID && p0.ldr >= (1LL << 22)) || ((epi == EP_ROWDOT || bits) && p0.ldg >= (1LL << 22))) return false;
+  if (epi != EP_PLAIN && (ta || tb)) return false;   // the fused epilogues exist for the K-contiguous products only
+  static int num_cus = 0;
+  if (!num_cus) {
+    hipDeviceProp_t prop; int dev = 0;
+    hipGetDevice(&dev); hipGetDeviceProperties(&prop, dev);
+    num_cus = prop.multiProcessorCount > 0 ? (prop.multiProcessorCount / 8) * 8 : 256;
+    if (num_cus < 8) num_cus = 8;
+  }
+  GemmP p = p0;
+  p.kchunk = p.K;
+  const long long nt = (p.M / E_BM) * (p.N / E_BN);
+  const unsigned G = (unsigned)(nt < num_cus ? ((nt + 7) / 8) * 8 : num_cus);
+  dim3 grid(G), block(512);
+  if (epi == EP_ROWDOT) hipMemsetAsync((void*)p.bias, 0, (size_t)p.M * (size_t)(p.N >> 7) * sizeof(float), st);  // the two waves of a 128-column block add into it
+#define LAUNCH_E(TA_, TB_, EP_, VAR_)                                                                                            \
+  do {                                                                                                                     \
+    static bool attr_set = false;                                                                                          \
+    if (!attr_set) {                                                                                                       \
+      hipFuncSetAttribute((const void*)gemm_bf16_e256<TA_, TB_, EP_, VAR_>, hipFuncAttributeMaxDynamicSharedMemorySize, E_LDS_BYTES); \
+      attr_set = true;                                                                                                     \
+    }                                                                                                                      \
+    hipLaunchKernelGGL((gemm_bf16_e256<TA_, TB_, EP_, VAR_>), grid, block, E_LDS_BYTES, st, p);                                  \
+  } while (0)
+  if (!ta && !tb) {
+    switch (epi) {
+      case EP_RELU: LAUNCH_E(false, false, EP_RELU, 0); break;
+      case EP_RESID: if (var == 2) LAUNCH_E(false, false, EP_RESID, 2); else LAUNCH_E(false, false, EP_RESID, 0); break;
+      case EP_RELU_BITS: LAUNCH_E(false, false, EP_RELU_BITS, 0); break;
+      case EP_GATE_BITS: LAUNCH_E(false, false, EP_GATE_BITS, 0); break;
+      case EP_ROWDOT: LAUNCH_E(false, false, EP_ROWDOT, 0); break;
+      default:
+        switch (var) {
+          case 2: LAUNCH_E(false, false, EP_PLAIN, 2); break;
+          case 4: LAUNCH_E(false, false, EP_PLAIN, 4); break;
+          case 8: LAUNCH_E(false, false, EP_PLAIN, 8); break;
+          case 10: LAUNCH_E(false, false, EP_PLAIN, 10); break;
+          case 12: LAUNCH_E(false, false, EP_PLAIN, 12); break;
+          case 32: LAUNCH_E(false, false, EP_PLAIN, 32); break;
+          default: LAUNCH_E(false, false, EP_PLAIN, 0); break;
+        }
+    }
+  }
+  else if (!ta && tb) LAUNCH_E(false, true, EP_PLAIN, 0);
+  else if (ta && tb) LAUNCH_E(true, true, EP_PLAIN, 0);
+  else LAUNCH_E(true, false, EP_PLAIN, 0);
+#undef LAUNCH_E
+  return true;
+}
