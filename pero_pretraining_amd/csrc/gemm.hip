@@ -378,11 +378,13 @@ static int g_splitk_nearest = 0;    // 1: k-slice count rounded to the nearest m
 static int g_gemm_persistent = 1;  // PERO_GEMM_TILE_V products: persistent w256 (epilogue under the next tile's first stage) instead of v256
 int g_pero_splitk_xcd = 1;  // one k-slice per XCD for split-K products (gemm_o.hip)
 extern int g_gemm_e_var;
-static int g_gemm_e256_min = 0;  // default policy: products with at least this many 256x256 tiles take the eight-phase kernel (0 = never)
+static int g_gemm_e_splitk_min = 4;  // ... and split-K products with at least this many output tiles
+static int g_gemm_e256_min = 192;  // default policy: products with at least this many 256x256 tiles take the eight-phase kernel (0 = never)
 extern "C" int pero_set_option(const char* name, int value) {
   if (name && !strcmp(name, "gemm_policy")) { g_gemm_policy = value; return PERO_OK; }
   if (name && !strcmp(name, "gemm_e_var")) { g_gemm_e_var = value; return PERO_OK; }
   if (name && !strcmp(name, "gemm_e256_min")) { g_gemm_e256_min = value; return PERO_OK; }
+  if (name && !strcmp(name, "gemm_e_splitk_min")) { g_gemm_e_splitk_min = value; return PERO_OK; }
   if (name && !strcmp(name, "splitk_xcd")) { g_pero_splitk_xcd = value; return PERO_OK; }
   if (name && !strcmp(name, "splitk_nearest")) { g_splitk_nearest = value; return PERO_OK; }
   if (name && !strcmp(name, "splitk_t256_min")) { g_splitk_t256_min = value; return PERO_OK; }
@@ -480,6 +482,13 @@ static int gemm_dispatch(const void* A, const void* B, void* C, const float* bia
     bool use256 = false;
     (void)t256;
     const int k_split_req = k_split;
+    // split-K weight gradients on the eight-phase 256x256x64 main loop (gemm_e.hip, EP_SPLITK): long k-slices, LDS-staged atomics
+    if (atomic && !forced0 && out_dtype == PERO_F32 && can256 &&
+        (g_gemm_policy == 20 || (g_gemm_policy == 0 && g_gemm_e256_min > 0 && K >= 32768 && t256 >= g_gemm_e_splitk_min)) &&
+        pero_launch_gemm_e256(p, batch, k_split_req, ta, tb, true, st, -1)) {
+      PERO_CHECK_LAUNCH("pero_gemm(e256 split-K)");
+      return PERO_OK;
+    }
     if (atomic && k_split == 0) {
       long long ks = (g_splitk_items + t128 - 1) / t128;
       if (ks > K / 512) ks = K / 512;

@@ -21,9 +21,10 @@
 //    the first K-tile's wait counts them out - the stores then have two K-tiles of main loop to drain.
 //  * Epilogue straight from the accumulators (no LDS, no barrier): operands are swapped in the MFMA so that a lane owns 4
 //    consecutive output columns of one row; v_permlane16_swap between the two 16 x 16 tiles of a 32-column block gives it 8
-//    consecutive columns -> one 16-byte store (64 contiguous bytes per row and instruction).  The bias is the accumulators'
-//    INITIAL value (a per-wave 1 KiB copy of the tile's bias row, fetched by one more LDS-DMA of the same stream: an
-//    ordinary load would have to wait for every LDS-DMA issued before it).  Side inputs (residual rows, the second matrix
+//    consecutive columns -> one 16-byte store (64 contiguous bytes per row and instruction).  The bias comes from a per-wave
+//    1 KiB LDS copy of the tile's bias row, fetched by one more LDS-DMA of the same stream at the tile's start (an
+//    ordinary load would have to wait for every LDS-DMA issued before it) and added in f32 before the rounding, exactly as
+//    the other tile kernels do (acc * alpha + bias): results are bit-identical across kernels, i.e. across batch sizes.  Side inputs (residual rows, the second matrix
 //    of the row dots, the ReLU bit mask) are fetched by inline-asm buffer loads the compiler does not count: half of them
 //    in phase 4 of the tile's last K-tile, half at the start of the epilogue, each waited for by a counted vmcnt.
 #include "gemm_common.hpp"
@@ -45,6 +46,7 @@
 #define EP_RELU_BITS 3   // bias, ReLU, `gate` receives the bit mask (stored C > 0)
 #define EP_GATE_BITS 4   // `gate` bit mask applied; with PERO_GEMM_COLSUM the column sums of the stored result are added to `bias`
 #define EP_ROWDOT 6      // `bias`[m][n / 128] += row dots of the stored result with `gate` (bf16 rows of C's shape)
+#define EP_SPLITK 7      // f32 C += partial product of ONE k-slice (atomics): one work item (tile, k-slice) per workgroup, not persistent
 
 typedef int ei4v __attribute__((ext_vector_type(4)));
 typedef unsigned eu4v __attribute__((ext_vector_type(4)));
@@ -93,6 +95,13 @@ __device__ __forceinline__ ei4v ersrc(const void* base, unsigned bytes) {
   asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4" : "=v"(dst_) : "v"(voff_), "s"(rs_), "s"(soff_), "i"(imm_) : "memory")
 #define E_BLOAD8(dst_, voff_, rs_, soff_, imm_) \
   asm volatile("s_nop 4\n\tbuffer_load_dwordx2 %0, %1, %2, %3 offen offset:%4" : "=v"(dst_) : "v"(voff_), "s"(rs_), "s"(soff_), "i"(imm_) : "memory")
+// 16-byte store: its data registers are rewritten by the next unit right behind it.  hipcc (ROCm 7.2) pads that hazard only for
+// a constant soffset; with the row offset in an SGPR the store sent stale dwords for some lanes (measured: lanes 12-15 of the
+// second data dword) - the wait states are in the string
+#define E_BSTORE16(src_, voff_, rs_, soff_, imm_) \
+  asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen offset:%4\n\ts_nop 2" :: "v"(src_), "v"(voff_), "s"(rs_), "s"(soff_), "i"(imm_) : "memory")
+#define E_BSTORE16_NT(src_, voff_, rs_, soff_, imm_) \
+  asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen offset:%4 nt\n\ts_nop 2" :: "v"(src_), "v"(voff_), "s"(rs_), "s"(soff_), "i"(imm_) : "memory")
 #define E_WAIT8(n_, r_) \
   asm volatile("s_waitcnt vmcnt(%8)" : "+v"(r_[0]), "+v"(r_[1]), "+v"(r_[2]), "+v"(r_[3]), "+v"(r_[4]), "+v"(r_[5]), "+v"(r_[6]), "+v"(r_[7]) : "i"(n_) : "memory")
 #define E_WAIT4(n_, r_) \
@@ -107,7 +116,7 @@ template <int EPI> struct ECnt {
 };
 
 template <bool TA, bool TB, int EPI, int VAR>
-__global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p) {
+__global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p, int ks) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   typedef ECnt<EPI> CN;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -119,7 +128,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p) {
   const int q8 = nt >> 3, r8 = nt & 7;
   const bf16raw* A = (const bf16raw*)p.A;
   const bf16raw* B = (const bf16raw*)p.B;
-  const int nk = (int)(p.K / E_BK);  // >= 2 (launcher)
+  int nk = (int)(p.K / E_BK);  // >= 2 (launcher); split-K: the work item's K-tiles (set below)
   const unsigned offA = elane_off<TA, true>(p.lda, tid), offB = elane_off<TB, false>(p.ldb, tid);
   const bool colsum = EPI == EP_GATE_BITS && (p.flags & PERO_GEMM_COLSUM);
 
@@ -130,11 +139,27 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p) {
     tn0 = (long long)(id % ntn) * E_BN;
   };
   int T = blockIdx.x;
-  if (T >= nt) return;
-  long long tm0, tn0, nm0, nn0;
-  tile_of(T, tm0, tn0);
-  bool has_next = T + G < nt;
-  tile_of(has_next ? T + G : T, nm0, nn0);
+  long long tm0, tn0, nm0, nn0, kbeg = 0;
+  bool has_next = false;
+  if (EPI == EP_SPLITK) {
+    // work item = (tile, k-slice); the slices of one XCD's workgroups are the same few (operand panels fetched once per L2)
+    const int xcd = T & 7, r = T >> 3;
+    int id, z;
+    if (ks < 0) { id = T / (-ks); z = T % (-ks); }  // any slice count: plain order
+    else if (ks >= 8) { const int per = ks >> 3; z = xcd * per + (r % per); id = r / per; }
+    else { z = xcd % ks; id = r * (8 / ks) + xcd / ks; }
+    tm0 = (long long)(id / ntn) * E_BM; tn0 = (long long)(id % ntn) * E_BN;
+    nm0 = tm0; nn0 = tn0;
+    // K-tiles are dealt evenly: the first (steps % slices) slices take one more
+    const int steps = (int)(p.K / E_BK), nsl = ks < 0 ? -ks : ks, base = steps / nsl, rem = steps % nsl;
+    nk = base + (z < rem ? 1 : 0);
+    kbeg = (long long)(z * base + (z < rem ? z : rem)) * E_BK;
+  } else {
+    if (T >= nt) return;
+    tile_of(T, tm0, tn0);
+    has_next = T + G < nt;
+    tile_of(has_next ? T + G : T, nm0, nn0);
+  }
 
   // fragment read addresses (per lane, relative to a half tile's base)
   //  K-contiguous image [128 rows][128 B]: row = row0 + (lane & 15), 16-byte chunk (4 s + (lane >> 4)) ^ (row & 7)
@@ -186,11 +211,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p) {
   // one; a workgroup's last tile "prefetches" its own first K-tiles again: the stream keeps its shape, no branches)
   const EStep<TA, 64> sa(p.lda);
   const EStep<TB, 32> sb(p.ldb);
-  const unsigned char* cA = (const unsigned char*)A + tm0 * sa.tile;
-  const unsigned char* cB = (const unsigned char*)B + tn0 * sb.tile;
+  const unsigned char* cA = (const unsigned char*)A + tm0 * sa.tile + (kbeg / E_BK) * sa.ktile;
+  const unsigned char* cB = (const unsigned char*)B + tn0 * sb.tile + (kbeg / E_BK) * sb.ktile;
   const unsigned char* nA = (const unsigned char*)A + nm0 * sa.tile;
   const unsigned char* nB = (const unsigned char*)B + nn0 * sb.tile;
   auto issue = [&](int u, int which, unsigned char* ktbase) {
+    if (EPI == EP_SPLITK && u >= nk) return;  // one work item: nothing follows (the ring is the epilogue's staging area)
     const bool nx = u >= nk;
     const long long uu = nx ? u - nk : u;
     unsigned char* dst = ktbase + which * E_HALF + wave * 1024;
@@ -215,7 +241,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p) {
     for (int i = 0; i < delay; i += 1024) __builtin_amdgcn_s_sleep(16);
   }
   // ---- prologue: K-tile 0 and all of K-tile 1 (a tile's A1(1) is always issued ahead of its first K-tile)
-  issue_bias(tn0);
   issue(0, 2, smem); issue(0, 0, smem); issue(0, 3, smem); issue(0, 1, smem);
   issue(1, 2, smem + E_KTILE); issue(1, 0, smem + E_KTILE); issue(1, 3, smem + E_KTILE); issue(1, 1, smem + E_KTILE);
   asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -241,20 +266,15 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p) {
   for (;;) {
     E_STAMP(0);
     E_STAMP(3);
-    // accumulators start at the bias (or zero): lane owns columns 64 wc + 32 hb + 16 j + 4 (lane >> 4) .. + 3
 #pragma unroll
-    for (int hb = 0; hb < 2; hb++)
+    for (int ha = 0; ha < 2; ha++)
 #pragma unroll
-      for (int j = 0; j < 2; j++) {
-        f4v b4 = (f4v){0.f, 0.f, 0.f, 0.f};
-        if (use_bias) b4 = *(const f4v*)(biasl + (64 * wc + 32 * hb + 16 * j + 4 * lq) * 4);
+      for (int hb = 0; hb < 2; hb++)
 #pragma unroll
-        for (int ha = 0; ha < 2; ha++)
+        for (int i = 0; i < 4; i++)
 #pragma unroll
-          for (int i = 0; i < 4; i++) acc[ha][hb][i][j] = b4;
-      }
-    E_LGKM0();
-    issue_bias(nn0);  // next tile's bias row: part of the stream (older than everything a later wait counts)
+          for (int j = 0; j < 2; j++) acc[ha][hb][i][j] = (f4v){0.f, 0.f, 0.f, 0.f};
+    issue_bias(tn0);  // this tile's bias row for its epilogue: part of the stream (older than everything a later wait counts)
 
     // side-input descriptor of this tile
     const int spitch = (int)(EPI == EP_RESID ? p.ldr * 2 : EPI == EP_ROWDOT ? p.ldg * 2 : p.ldg);  // bytes per row
@@ -315,9 +335,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p) {
       // K-tile t+1 has landed (this wave's pieces).  What was issued after its last half tile A1(t+1) stays in flight:
       // normally the three half tiles of t+2; in a tile's first K-tile also the previous epilogue (side loads of rows 64-127,
       // stores) and the bias row; in its last K-tile the side loads issued just above.
-      if (!last && t == 0 && !first && colsum) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(6 + 1 + CN::L1 + 2 * CN::S_HALF + 16) : "memory");  // + the 16 column-sum atomics
+      if (!last && t == 0 && first) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");  // + the bias row
+      else if (!last && t == 0 && !first && colsum) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(6 + 1 + CN::L1 + 2 * CN::S_HALF + 16) : "memory");  // + the 16 column-sum atomics
       else if (!last && t == 0 && !first) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(6 + 1 + CN::L1 + 2 * CN::S_HALF) : "memory");
       else if (CN::L0 && last) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(6 + CN::L0) : "memory");
+      else if (EPI == EP_SPLITK && t + 2 >= nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stream has ended
       else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
       E_BAR();
       E_MFMA(1, 0, fb0);
@@ -331,9 +353,49 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p) {
     E_STAMP(1);
     first = false;
     issue(nk + 1, 1, smem + (d ^ 1) * E_KTILE);  // A1 of the next tile's K-tile 1: ahead of the stores in the in-order counter
+    if (EPI == EP_SPLITK) {
+      // f32 tile added into C with atomics whose wave-instructions cover 256 contiguous bytes (full atomic rate): two rounds
+      // through the (now free) 128 KiB ring, [128 rows][256 f32], 16-byte chunk index XORed with (row & 15)
+      if (wr == 0) { E_BAR(); }  // undo the stagger: every wave has finished its last reads and MFMAs
+      float* const C = (float*)p.C;
+#pragma unroll
+      for (int ha = 0; ha < 2; ha++) {
+        if (ha) { E_LGKM0(); E_BAR(); }
+#pragma unroll
+        for (int hb = 0; hb < 2; hb++)
+#pragma unroll
+          for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+              const int row = 64 * wr + 16 * i + li, chunk = 16 * wc + 8 * hb + 4 * j + lq;
+              *(f4v*)(smem + row * 1024 + ((chunk ^ (row & 15)) << 4)) = acc[ha][hb][i][j];
+            }
+        E_LGKM0();
+        E_BAR();
+        // staged row r = 64 * wr' + rr  <->  tile row 128 * wr' + 64 * ha + rr
+#pragma unroll 4
+        for (int it = 0; it < 64; it++) {
+          const int item = it * 8 + wave, row = item >> 2, seg = item & 3;
+          const int col = 64 * seg + lane;
+          const float v = *(const float*)(smem + row * 1024 + ((((col >> 2)) ^ (row & 15)) << 4) + (col & 3) * 4);
+          const long long grow = tm0 + 128 * (row >> 6) + 64 * ha + (row & 63);
+          atomicAdd(C + grow * p.ldc + tn0 + col, v);
+        }
+      }
+      return;
+    }
     {
-      const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc((bf16raw*)p.C + tm0 * p.ldc + tn0, 0, (int)(256 * p.ldc * 2), 0x00020000);
+      const ei4v crs = ersrc((bf16raw*)p.C + tm0 * p.ldc + tn0, (unsigned)(256 * p.ldc * 2));
       const int cpitch = (int)(p.ldc * 2);
+      // bias of the lane's columns as the accumulators hold them: 64 wc + 32 hb + 16 j + 4 (lane >> 4) .. + 3
+      f4v bx[2][2];
+#pragma unroll
+      for (int hb = 0; hb < 2; hb++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          bx[hb][j] = (f4v){0.f, 0.f, 0.f, 0.f};
+          if (use_bias) bx[hb][j] = *(const f4v*)(biasl + (64 * wc + 32 * hb + 16 * j + 4 * lq) * 4);
+        }
       float cs[2][8];  // EP_GATE_BITS + column sums
       float rd[4];     // EP_ROWDOT: row dots of one row group
 #pragma unroll
@@ -371,7 +433,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p) {
           if (EPI == EP_ROWDOT) rd[i] = 0.f;
 #pragma unroll
           for (int hb = 0; hb < 2; hb++) {
-            const f4v x = acc[ha][hb][i][0], y = acc[ha][hb][i][1];
+            const f4v x = acc[ha][hb][i][0] + bx[hb][0], y = acc[ha][hb][i][1] + bx[hb][1];  // (alpha = 1: the other kernels' acc * alpha + bias, bit for bit)
             eu4v o;
             if (EPI == EP_RESID) {
               // f32 columns first (one rounding): even lane groups keep x and take the odd neighbour's x, odd ones y
@@ -428,9 +490,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p) {
             }
             if (VAR & 4) {  // ablation: no stores (the values stay live)
               asm volatile("" :: "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]));
-              if (i + hb == 0) __builtin_amdgcn_raw_buffer_store_b128(o, crs, cvo + 64 * hb, so, 0);
+              if (i + hb == 0) { if (hb) E_BSTORE16(o, cvo, crs, so, 64); else E_BSTORE16(o, cvo, crs, so, 0); }
+            } else if (VAR & 32) {
+              if (hb) E_BSTORE16_NT(o, cvo, crs, so, 64); else E_BSTORE16_NT(o, cvo, crs, so, 0);
             } else {
-              __builtin_amdgcn_raw_buffer_store_b128(o, crs, cvo + 64 * hb, so, (VAR & 16) ? 16 : (VAR & 32) ? 2 : 0);
+              if (hb) E_BSTORE16(o, cvo, crs, so, 64); else E_BSTORE16(o, cvo, crs, so, 0);
             }
           }
           if (EPI == EP_RELU_BITS) {
@@ -497,9 +561,46 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p) {
 // Qualifies: one problem (batch 1), no split-K, bf16 stored output, alpha == 1, M % 256 == N % 256 == K % 64 == 0, K >= 128.
 int g_gemm_e_var = 0;
 bool pero_launch_gemm_e256(const GemmP& p0, long long batch, int k_split, bool ta, bool tb, bool out_f32, hipStream_t st, int var) {
-  if (p0.M % E_BM || p0.N % E_BN || p0.K % E_BK || p0.K < 2 * E_BK || batch != 1 || k_split > 1 || out_f32) return false;
-  if (p0.flags & (PERO_GEMM_ATOMIC | PERO_GEMM_ACCUM)) return false;
+  if (p0.M % E_BM || p0.N % E_BN || p0.K % E_BK || p0.K < 2 * E_BK || batch != 1) return false;
   if (var < 0) var = g_gemm_e_var;
+  int ks = 0;
+  if (p0.flags & PERO_GEMM_ATOMIC) {
+    // split-K: f32 C, plain product, equal slices of whole K-tiles, one slice set per XCD
+    if (!out_f32 || p0.alpha != 1.0f || p0.bias || p0.resid || p0.gate || (p0.flags & ~(PERO_GEMM_ATOMIC | PERO_GEMM_TRANS_A | PERO_GEMM_TRANS_B | PERO_GEMM_TILE_V))) return false;
+    const long long tiles = (p0.M / E_BM) * (p0.N / E_BN), steps = p0.K / E_BK;
+    ks = k_split;
+    if (ks <= 0) {  // the library chooses: one round of workgroups over the CUs
+      ks = (int)(256 / tiles);
+      if (ks >= 8) ks = (ks / 8) * 8; else if (ks >= 4) ks = 4; else if (ks >= 2) ks = 2; else ks = 1;
+    }
+    if (k_split <= 0) {
+      // an XCD-aligned slice count (one slice set per XCD: operand panels fetched once per L2) when it fills >= 90 % of the CUs
+      // that the plain count fills, else the plain count
+      int kx = (int)(256 / tiles);
+      kx = kx < 1 ? 1 : kx;
+      if (ks * tiles * 10 < kx * tiles * 9) ks = kx;
+    }
+    while (ks > 1 && steps / ks < 2) ks--;
+    const bool xcd_ok = (ks == 1 || ks == 2 || ks == 4 || ks % 8 == 0) && (tiles * ks) % 8 == 0 && (ks >= 8 || tiles % (8 / ks) == 0);
+    if (p0.lda >= (1LL << 22) || p0.ldb >= (1LL << 22)) return false;
+    GemmP p = p0;
+    p.kchunk = 0;
+    dim3 grid((unsigned)(tiles * ks)), block(512);
+    if (!xcd_ok) ks = -ks;
+#define LAUNCH_ES(TA_, TB_)                                                                                                \
+  do {                                                                                                                     \
+    static bool attr_set = false;                                                                                          \
+    if (!attr_set) {                                                                                                       \
+      hipFuncSetAttribute((const void*)gemm_bf16_e256<TA_, TB_, EP_SPLITK, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, E_LDS_BYTES); \
+      attr_set = true;                                                                                                     \
+    }                                                                                                                      \
+    hipLaunchKernelGGL((gemm_bf16_e256<TA_, TB_, EP_SPLITK, 0>), grid, block, E_LDS_BYTES, st, p, ks);                    \
+  } while (0)
+    if (!ta && !tb) LAUNCH_ES(false, false); else if (!ta && tb) LAUNCH_ES(false, true); else if (ta && tb) LAUNCH_ES(true, true); else LAUNCH_ES(true, false);
+#undef LAUNCH_ES
+    return true;
+  }
+  if (k_split > 1 || out_f32 || (p0.flags & PERO_GEMM_ACCUM)) return false;
   if (p0.alpha != 1.0f) return false;
   if (p0.lda >= (1LL << 22) || p0.ldb >= (1LL << 22) || p0.ldc >= (1LL << 22)) return false;  // 32-bit byte offsets inside a tile
   const bool relu = p0.flags & PERO_GEMM_RELU, bits = p0.flags & PERO_GEMM_RELU_BITS, rowdot = p0.flags & PERO_GEMM_ROWDOT,
@@ -533,7 +634,7 @@ bool pero_launch_gemm_e256(const GemmP& p0, long long batch, int k_split, bool t
       hipFuncSetAttribute((const void*)gemm_bf16_e256<TA_, TB_, EP_, VAR_>, hipFuncAttributeMaxDynamicSharedMemorySize, E_LDS_BYTES); \
       attr_set = true;                                                                                                     \
     }                                                                                                                      \
-    hipLaunchKernelGGL((gemm_bf16_e256<TA_, TB_, EP_, VAR_>), grid, block, E_LDS_BYTES, st, p);                                  \
+    hipLaunchKernelGGL((gemm_bf16_e256<TA_, TB_, EP_, VAR_>), grid, block, E_LDS_BYTES, st, p, ks);                                  \
   } while (0)
   if (!ta && !tb) {
     switch (epi) {

@@ -14,7 +14,7 @@ def bench(fn, iters=10):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters * 1e3
 tot = {p: 0.0 for p in pols}
-for (N, K, tag) in [(1536, 512, "qkv"), (512, 512, "out"), (2048, 512, "ffn1"), (512, 2048, "ffn2")]:
+for (N, K, tag) in [(1536, 512, "qkv"), (512, 512, "out"), (2048, 512, "ffn1"), (512, 2048, "ffn2"), (4096, 512, "head"), (512, 1024, "patch")]:
     x = (torch.randn(M, K, device="cuda") * 0.5).bfloat16(); dy = (torch.randn(M, N, device="cuda") * 0.5).bfloat16()
     fl = 2.0 * M * N * K
     res, outs = {}, {}
@@ -26,6 +26,9 @@ for (N, K, tag) in [(1536, 512, "qkv"), (512, 512, "out"), (2048, 512, "ffn1"), 
             outs[p] = dw.clone()
             res[p] = min(res.get(p, 1e9), bench(lambda: ops.gemm(dy, x, out=dw, trans_a=True, trans_b=True, atomic=True, k_split=0)))
     for p in pols: tot[p] += res[p]
+    ref = dy[:8192].float().t() @ x[:8192].float() if M <= 8192 else None
     err = max((outs[p] - outs[pols[0]]).abs().max().item() for p in pols)
+    if ref is not None:
+        err = max((outs[p] - ref).abs().max().item() for p in pols)
     print(f"{tag:5s} TT dW [{N}x{K}] over {M}: " + " | ".join(f"p{p}: {res[p]:6.1f} us {fl/res[p]/1e6:6.0f} TF" for p in pols) + f"  (max diff {err:.2e})")
 print("sum: " + " | ".join(f"p{p}: {tot[p]:7.1f} us" for p in pols))
