@@ -37,7 +37,7 @@
 #define E_KTILE (4 * E_HALF)       // A0 A1 B0 B1
 #define E_RING (2 * E_KTILE)       // 128 KiB: two K-tiles
 #define E_BIAS E_RING              // 8 x 1 KiB: each wave's copy of the tile's 256 bias floats
-#define E_LDS_BYTES (E_RING + 8192)
+#define E_LDS_BYTES (E_RING + 8192 + 512)   // + 512 B of phase stamps (diagnostic build VAR 64)
 
 // epilogue modes
 #define EP_PLAIN 0       // bias
@@ -110,7 +110,7 @@ __device__ __forceinline__ ei4v ersrc(const void* base, unsigned bytes) {
 template <int EPI> struct ECnt {
   // vector-memory operations of the epilogue, in issue order: side loads of rows 0-63 (phase 4 of the last K-tile), [A1 of the
   // next tile's K-tile 1], side loads of rows 64-127, then the stores / atomics of the two halves
-  static constexpr int L0 = (EPI == EP_RESID || EPI == EP_ROWDOT) ? 8 : (EPI == EP_GATE_BITS ? 4 : 0);
+  static constexpr int L0 = (EPI == EP_RESID || EPI == EP_ROWDOT) ? 8 : 0;  // (EP_GATE_BITS: its 8 mask loads go out in phase 1 of the last K-tile, ahead of A1(t+1): every later wait retires them)
   static constexpr int L1 = L0;
   static constexpr int S_HALF = 8 + (EPI == EP_RELU_BITS ? 4 : 0) + (EPI == EP_ROWDOT ? 4 : 0);
 };
@@ -255,6 +255,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p, int ks) {
   if (VAR & 8) stamp = (unsigned long long*)p.gate + ((size_t)blockIdx.x * 2 + wr) * 64 * 4;
 #define E_STAMP(k_) if ((VAR & 8) && wc == 0 && lane == 0 && tix < 64) stamp[tix * 4 + (k_)] = (k_) == 3 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime();
 
+  // VAR 64 (diagnostic build): s_memtime at 17 points of ONE K-tile (tile PT_TILE, K-tile PT_K) of waves 0 and 4, through LDS
+  // (a global store would enter the counted vmcnt stream) -> p.gate as u64 [G][2][32] at the end of the kernel
+  bool pst_on = false;
+#define E_PST(n_) if ((VAR & 64) && pst_on && wc == 0 && lane == 0) ((volatile unsigned long long*)(smem + E_RING + 8192))[wr * 32 + (n_)] = __builtin_amdgcn_s_memtime();
+
   // epilogue addressing: after the column swap a lane holds columns c8 .. c8 + 7 of a 32-column block of row li
   const int cq = ((lq & 1) << 1) | (lq >> 1), c8 = 8 * cq;
   const unsigned cvo = (unsigned)(((128 * wr + li) * p.ldc + 64 * wc + c8) * 2);   // C
@@ -289,46 +294,60 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p, int ks) {
       constexpr bool last = decltype(last_c)::value;
       unsigned char* const kt = smem + d * E_KTILE;         // K-tile t
       unsigned char* const kn = smem + (d ^ 1) * E_KTILE;   // K-tiles t + 1 (being completed) and, slot by slot, t + 2
+      if (VAR & 64) pst_on = (tix == ((VAR & 8) ? 2 : 0)) && t == (nk > 4 ? 4 : 1);
       // P1
+      E_PST(0);
       E_RD_B(fb0, 0);
       __builtin_amdgcn_sched_barrier(0);
       E_RD_A(0);
+      if (EPI == EP_GATE_BITS && last) {  // the tile's mask bytes (8 per row and wave): 8 small loads, four phases ahead of the epilogue
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const int so0 = 16 * i * spitch, so1 = (64 + 16 * i) * spitch;
+          E_BLOAD8(sm0[i], mvo, srs, so0, 0);
+          E_BLOAD8(sm1[i], mvo, srs, so1, 0);
+        }
+      }
       if (last || t > 0) issue(t + 1, 1, kn);                       // A1(t+1)  (a tile's A1(1) went out ahead of the previous epilogue)
       if (TA) asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");  // the B0 reads (issued first) are done: B0 may be restaged in P2
       else asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+      E_PST(1);
       E_BAR();
       E_LGKM0();
+      E_PST(2);
       E_MFMA(0, 0, fb0);
+      E_PST(3);
       E_BAR();
+      E_PST(4);
       // P2
       E_RD_B(fb1, 1);
       issue(t + 2, 2, kt);                                  // B0(t+2)
+      E_PST(5);
       E_BAR();
       E_LGKM0();
+      E_PST(6);
       E_MFMA(0, 1, fb1);
+      E_PST(7);
       E_BAR();
+      E_PST(8);
       // P3
       E_RD_A(1);
       issue(t + 2, 0, kt);                                  // A0(t+2)
+      E_PST(9);
       E_BAR();
       E_LGKM0();
+      E_PST(10);
       E_MFMA(1, 1, fb1);
+      E_PST(11);
       E_BAR();
+      E_PST(12);
       // P4
       if (CN::L0 && last) {  // side inputs of the wave's rows 0-63
-        if (EPI == EP_GATE_BITS) {
 #pragma unroll
-          for (int i = 0; i < 4; i++) {
-            const int so = 16 * i * spitch;
-            E_BLOAD8(sm0[i], mvo, srs, so, 0);
-          }
-        } else {
-#pragma unroll
-          for (int i = 0; i < 4; i++) {
-            const int so = 16 * i * spitch;
-            E_BLOAD16(side0[2 * i], gvo, srs, so, 0);
-            E_BLOAD16(side0[2 * i + 1], gvo, srs, so, 64);
-          }
+        for (int i = 0; i < 4; i++) {
+          const int so = 16 * i * spitch;
+          E_BLOAD16(side0[2 * i], gvo, srs, so, 0);
+          E_BLOAD16(side0[2 * i + 1], gvo, srs, so, 64);
         }
       }
       issue(t + 2, 3, kt);                                  // B1(t+2)
@@ -341,9 +360,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p, int ks) {
       else if (CN::L0 && last) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(6 + CN::L0) : "memory");
       else if (EPI == EP_SPLITK && t + 2 >= nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stream has ended
       else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      E_PST(13);
       E_BAR();
+      E_PST(14);
       E_MFMA(1, 0, fb0);
+      E_PST(15);
       E_BAR();
+      E_PST(16);
       d ^= 1;
     };
     for (int t = 0; t < nk - 1; t++) ktile(std::false_type{}, t);
@@ -357,6 +380,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p, int ks) {
       // f32 tile added into C with atomics whose wave-instructions cover 256 contiguous bytes (full atomic rate): two rounds
       // through the (now free) 128 KiB ring, [128 rows][256 f32], 16-byte chunk index XORed with (row & 15)
       if (wr == 0) { E_BAR(); }  // undo the stagger: every wave has finished its last reads and MFMAs
+      if ((VAR & 64) && wc == 0 && lane < 17)
+        ((unsigned long long*)p.gate)[((size_t)blockIdx.x * 2 + wr) * 32 + lane] = ((unsigned long long*)(smem + E_RING + 8192))[wr * 32 + lane];
       float* const C = (float*)p.C;
 #pragma unroll
       for (int ha = 0; ha < 2; ha++) {
@@ -405,26 +430,18 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p, int ks) {
 #pragma unroll
       for (int ha = 0; ha < 2; ha++) {
         if (CN::L1 && ha == 0) {  // side inputs of rows 64-127, then wait for those of rows 0-63
-          if (EPI == EP_GATE_BITS) {
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-              const int so = (64 + 16 * i) * spitch;
-              E_BLOAD8(sm1[i], mvo, srs, so, 0);
-            }
-            E_WAIT4(2 + 2 + CN::L1, sm0);
-          } else {
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-              const int so = (64 + 16 * i) * spitch;
-              E_BLOAD16(side1[2 * i], gvo, srs, so, 0);
-              E_BLOAD16(side1[2 * i + 1], gvo, srs, so, 64);
-            }
-            E_WAIT8(2 + 2 + CN::L1, side0);
+          for (int i = 0; i < 4; i++) {
+            const int so = (64 + 16 * i) * spitch;
+            E_BLOAD16(side1[2 * i], gvo, srs, so, 0);
+            E_BLOAD16(side1[2 * i + 1], gvo, srs, so, 64);
           }
+          E_WAIT8(2 + 2 + CN::L1, side0);
         }
-        if (CN::L1 && ha == 1) {
-          if (EPI == EP_GATE_BITS) E_WAIT4(CN::S_HALF, sm1);
-          else E_WAIT8(CN::S_HALF, side1);
+        if (CN::L1 && ha == 1) E_WAIT8(CN::S_HALF, side1);
+        if (EPI == EP_GATE_BITS && ha == 0) {  // landed long ago (retired by phase 4's wait); the statement ties the registers to it
+          E_WAIT4(63, sm0);
+          E_WAIT4(63, sm1);
         }
 #pragma unroll
         for (int i = 0; i < 4; i++) {
@@ -548,6 +565,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p, int ks) {
     nA = (const unsigned char*)A + nm0 * sa.tile;
     nB = (const unsigned char*)B + nn0 * sb.tile;
   }
+  if ((VAR & 64) && wc == 0 && lane < 17)
+    ((unsigned long long*)p.gate)[(VAR & 8 ? (size_t)gridDim.x * 2 * 64 * 4 : 0) + ((size_t)blockIdx.x * 2 + wr) * 32 + lane] = ((unsigned long long*)(smem + E_RING + 8192))[wr * 32 + lane];
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last tile's surplus prefetches land before the LDS is released
   if (wr == 0) { E_BAR(); }  // balance the stagger barrier
 #undef E_RD_A
@@ -566,7 +585,7 @@ bool pero_launch_gemm_e256(const GemmP& p0, long long batch, int k_split, bool t
   int ks = 0;
   if (p0.flags & PERO_GEMM_ATOMIC) {
     // split-K: f32 C, plain product, equal slices of whole K-tiles, one slice set per XCD
-    if (!out_f32 || p0.alpha != 1.0f || p0.bias || p0.resid || p0.gate || (p0.flags & ~(PERO_GEMM_ATOMIC | PERO_GEMM_TRANS_A | PERO_GEMM_TRANS_B | PERO_GEMM_TILE_V))) return false;
+    if (!out_f32 || p0.alpha != 1.0f || p0.bias || p0.resid || (p0.gate && !(var & 64)) || (p0.flags & ~(PERO_GEMM_ATOMIC | PERO_GEMM_TRANS_A | PERO_GEMM_TRANS_B | PERO_GEMM_TILE_V))) return false;
     const long long tiles = (p0.M / E_BM) * (p0.N / E_BN), steps = p0.K / E_BK;
     ks = k_split;
     if (ks <= 0) {  // the library chooses: one round of workgroups over the CUs
@@ -596,6 +615,12 @@ bool pero_launch_gemm_e256(const GemmP& p0, long long batch, int k_split, bool t
     }                                                                                                                      \
     hipLaunchKernelGGL((gemm_bf16_e256<TA_, TB_, EP_SPLITK, 0>), grid, block, E_LDS_BYTES, st, p, ks);                    \
   } while (0)
+    if ((var & 64) && ta && tb) {
+      static bool attr64 = false;
+      if (!attr64) { hipFuncSetAttribute((const void*)gemm_bf16_e256<true, true, EP_SPLITK, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, E_LDS_BYTES); attr64 = true; }
+      hipLaunchKernelGGL((gemm_bf16_e256<true, true, EP_SPLITK, 64>), grid, block, E_LDS_BYTES, st, p, ks);
+      return true;
+    }
     if (!ta && !tb) LAUNCH_ES(false, false); else if (!ta && tb) LAUNCH_ES(false, true); else if (ta && tb) LAUNCH_ES(true, true); else LAUNCH_ES(true, false);
 #undef LAUNCH_ES
     return true;
@@ -651,6 +676,7 @@ bool pero_launch_gemm_e256(const GemmP& p0, long long batch, int k_split, bool t
           case 10: LAUNCH_E(false, false, EP_PLAIN, 10); break;
           case 12: LAUNCH_E(false, false, EP_PLAIN, 12); break;
           case 32: LAUNCH_E(false, false, EP_PLAIN, 32); break;
+          case 72: LAUNCH_E(false, false, EP_PLAIN, 72); break;
           default: LAUNCH_E(false, false, EP_PLAIN, 0); break;
         }
     }
