@@ -37,10 +37,9 @@ extern "C" {
 #define PERO_GEMM_ACCUM 4       /* f32 C only: C += result (non-atomic) */
 #define PERO_GEMM_TRANS_A 8     /* A is stored [K][M] (lda = row pitch of that storage) */
 #define PERO_GEMM_TRANS_B 16    /* B is stored [K][N]; default B is stored [N][K] (Linear weight layout) */
-#define PERO_GEMM_TILE128 64     /* benchmarking: force the 128x128-tile bf16 kernel */
-#define PERO_GEMM_TILE256 128    /* benchmarking: force the 256x256-tile bf16 kernel (when the shape allows) */
-#define PERO_GEMM_TILE_S 256     /* benchmarking: force the 128x128x32 four-workgroups-per-CU kernel */
-#define PERO_GEMM_TILE_V 512     /* prefer the 256x256x64 one-workgroup-per-CU kernel (whole GPU to itself: forward pass) */
+#define PERO_GEMM_TILE128 64     /* force the persistent 128x128x64 bf16 kernel */
+#define PERO_GEMM_TILE256 128    /* take the eight-phase 256x256x64 kernel whatever the tile count (when the shape allows: M, N % 256, K % 64, K >= 128) */
+#define PERO_GEMM_TILE_V 512     /* accepted, no effect (a round-1 tile hint) */
 #define PERO_GEMM_ROWDOT 4096   /* bf16 C, N % 128 == 0: `gate` is a bf16 matrix of C's shape that is NOT applied as a gate, and `bias`
                                  * is an OUTPUT (f32 [M][N/128]): bias[m][b] = sum over columns 128b..128b+127 of C[m][c] * gate[m][c],
                                  * with C as stored (bf16).  The attention backward's D = rowsum(dO * O) per head, out of the
@@ -56,9 +55,9 @@ extern "C" {
 
 const char* pero_last_error(void);
 int pero_abi_version(void);
-/* tuning knobs for benchmarking (A/B of kernel variants; defaults are the measured best): "gemm_policy" (0 = auto, 1..16 =
- * force one tile-kernel family, table in csrc/gemm.hip), "gemm_persistent" (1), "splitk_items" (512), "splitk_xcd" (1), "splitk_t256_min" (8: split-K weight
- * gradients with at least that many 256x256 output tiles and a reduction of >= 131072 rows take the 256x256x64 kernel; 0 = never),
+/* tuning knobs for benchmarking and tests (defaults are the measured best): "gemm_policy" (0 = auto, 1 / 4 / 7 / 20 = force one tile-kernel
+ * family, table in csrc/gemm.hip), "gemm_e256_min" (192: stored products with at least that many 256x256 tiles take the eight-phase
+ * kernel; 0 = never), "gemm_e_splitk_min" (4), "gemm_e_var" (diagnostic builds of that kernel), "splitk_items" (512), "splitk_xcd" (1),
  * "splitk_nearest" (0).  Process-wide; not meant to be changed while products are in flight. */
 int pero_set_option(const char* name, int value);
 

@@ -355,31 +355,23 @@ __global__ __launch_bounds__(256) void gemm_generic(GemmP p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Tile-kernel policy, chosen by interleaved same-process A/B of the WHOLE training step (tools/step_ab2.py; isolated
-// hot-cache micro-benchmarks rank the variants differently, and devices differ by a few % between runs):
-//   0 = default:
-//         * products flagged PERO_GEMM_TILE_V (forward pass: they have the GPU to themselves) with >= 192 tiles of 256x256
-//           -> gemm_bf16_w256 (persistent 256x256x64; "gemm_persistent" = 0: gemm_bf16_v256, one tile per workgroup)
-//         * other products with a stored output -> gemm_bf16_r256 (256x128x32, 8 waves, two workgroups per CU) when M is a
-//           multiple of 256, else gemm_bf16_s128 (128x128x32, three workgroups per CU)
-//         * split-K atomic products (weight gradients) -> gemm_bf16_o128 (128x128x64, one tile per workgroup, one k-slice
-//           per XCD), k-slices aimed at "splitk_items" = 512 workgroups
-//   A/B baselines: 1 = persistent 128-tile with deferred epilogue, 2 = 256-tile 8 waves, 3 = s128, 4 = all o128, 6 = shape mix
-//   of 2/3, 7 = r256, 8 = q256 (16-wave 256x256x32), 9 = p128 software-pipelined, 10 = v256 for every stored output,
-//   11 = v256 for K >= 1024, 12 = w256 for every stored output, 13 / 14 = 256x256 / 256x128 split-K tiles for the weight
-//   gradients, 15 = x256 (four waves, 128x128 wave tiles, NT only).  Measurements: DESIGN.md section 8.
-static int g_gemm_policy = 0;
-static int g_splitk_items = 512;     // workgroups the automatic split-K aims for (k_split = 0)
-static int g_splitk_t256_min = 8;    // > 0: split-K weight gradients with at least this many 256x256 output tiles and a reduction of >= 131072
-                                     // rows take gemm_bf16_v256 (256x256x64 tiles, one k-slice round): step 48.9 -> 47.7 ms at 512 lines per GPU;
-                                     // shorter reductions (<= 256 lines) stay on the 128x128 kernel, which is 0.4 - 3 % faster there
-static int g_splitk_nearest = 0;    // 1: k-slice count rounded to the nearest multiple of 8 instead of up (faster alone for the
-                                    // 48-tile in_proj gradient, 0.1 ms slower inside the step: tools/splitk_ab.py)
-static int g_gemm_persistent = 1;  // PERO_GEMM_TILE_V products: persistent w256 (epilogue under the next tile's first stage) instead of v256
-int g_pero_splitk_xcd = 1;  // one k-slice per XCD for split-K products (gemm_o.hip)
+// Tile-kernel policy ("gemm_policy"; measurements: DESIGN.md section 8):
+//   0 = auto:
+//         * stored bf16 products with >= "gemm_e256_min" (192) tiles of 256x256 - and those flagged PERO_GEMM_TILE256 -> the
+//           eight-phase persistent 256x256x64 kernel gemm_bf16_e256 (gemm_e.hip) with its fused epilogues;
+//         * split-K atomic products (weight gradients) over >= 32768 reduction rows with >= "gemm_e_splitk_min" (4) output tiles
+//           -> gemm_bf16_e256 in its split-K mode; shorter ones -> gemm_bf16_o128 (128x128x64, one tile per workgroup, one
+//           k-slice per XCD), k-slices aimed at "splitk_items" (512) workgroups;
+//         * other stored products -> gemm_bf16_r256 (256x128x32, two workgroups per CU: small batches) when M is a multiple
+//           of 256, else the persistent 128x128x64 kernel of this file (also: batched products, PERO_GEMM_TILE128);
+//   forcing one family for A/B runs and tests: 1 = 128x128x64 persistent, 4 = o128, 7 = r256, 20 = e256 (any tile count).
 extern int g_gemm_e_var;
-static int g_gemm_e_splitk_min = 4;  // ... and split-K products with at least this many output tiles
-static int g_gemm_e256_min = 192;  // default policy: products with at least this many 256x256 tiles take the eight-phase kernel (0 = never)
+static int g_gemm_policy = 0;         // 0 = auto, 1 = 128x128x64 persistent kernel (this file), 4 = gemm_bf16_o128, 7 = gemm_bf16_r256, 20 = gemm_bf16_e256
+static int g_gemm_e256_min = 192;     // auto: stored products with at least this many 256x256 tiles take the eight-phase kernel (0 = never)
+static int g_gemm_e_splitk_min = 4;   // ... and split-K products (reduction >= 32768 rows) with at least this many output tiles
+static int g_splitk_items = 512;      // split-K of the 128x128 kernel aims at this many work items
+static int g_splitk_nearest = 0;
+int g_pero_splitk_xcd = 1;            // one k-slice per XCD where the slice count allows it (gemm_o.hip)
 extern "C" int pero_set_option(const char* name, int value) {
   if (name && !strcmp(name, "gemm_policy")) { g_gemm_policy = value; return PERO_OK; }
   if (name && !strcmp(name, "gemm_e_var")) { g_gemm_e_var = value; return PERO_OK; }
@@ -387,9 +379,7 @@ extern "C" int pero_set_option(const char* name, int value) {
   if (name && !strcmp(name, "gemm_e_splitk_min")) { g_gemm_e_splitk_min = value; return PERO_OK; }
   if (name && !strcmp(name, "splitk_xcd")) { g_pero_splitk_xcd = value; return PERO_OK; }
   if (name && !strcmp(name, "splitk_nearest")) { g_splitk_nearest = value; return PERO_OK; }
-  if (name && !strcmp(name, "splitk_t256_min")) { g_splitk_t256_min = value; return PERO_OK; }
-  if (name && !strcmp(name, "gemm_persistent")) { g_gemm_persistent = value; return PERO_OK; }
-  if (name && !strcmp(name, "splitk_items")) { g_splitk_items = value > 0 ? value : 256; return PERO_OK; }
+  if (name && !strcmp(name, "splitk_items")) { g_splitk_items = value > 0 ? value : 512; return PERO_OK; }
   pero_set_error("pero_set_option: unknown option %s", name ? name : "(null)");
   return PERO_E_INVALID;
 }
@@ -454,41 +444,36 @@ static int gemm_dispatch(const void* A, const void* B, void* C, const float* bia
               (sAo % 8 == 0) && (sAi % 8 == 0) && (sBo % 8 == 0) && (sBi % 8 == 0) && ((sCo * esz_o) % 16 == 0) &&
               ((sCi * esz_o) % 16 == 0) && (!residual || (ldr % 8 == 0 && aligned16(residual))) &&
               (!gate || (flags & PERO_GEMM_RELU_BITS) || (ldg % 8 == 0 && aligned16(gate))) && (!(residual || gate) || out_dtype == PERO_BF16 || true);
-  if (fast && !(flags & (PERO_GEMM_TILE128 | PERO_GEMM_TILE256 | PERO_GEMM_TILE_S))) {
-    if (g_gemm_policy == 1) flags |= PERO_GEMM_TILE128;
-    else if (g_gemm_policy == 2) flags |= PERO_GEMM_TILE256;
-    else if (g_gemm_policy == 3) flags |= PERO_GEMM_TILE_S;
-    p.flags = flags;
-    pc.flags = flags | cs_bits;
-  }
-  const bool forced0 = flags & (PERO_GEMM_TILE128 | PERO_GEMM_TILE256 | PERO_GEMM_TILE_S);
+  if (fast && g_gemm_policy == 1) { flags |= PERO_GEMM_TILE128; p.flags = flags; pc.flags = flags | cs_bits; }
+  const bool force128 = flags & PERO_GEMM_TILE128, force256 = flags & PERO_GEMM_TILE256;
   if (flags & PERO_GEMM_RELU_BITS) {
-    // bit-mask ReLU gate: only the w256 / v256 / r256 epilogues read or write it, and the default policy reaches one of
-    // them exactly under these conditions
-    PERO_REQUIRE(fast && gate && batch == 1 && out_dtype == PERO_BF16 && !ta && !(flags & PERO_GEMM_ATOMIC) && !forced0 && M % 256 == 0 &&
-                 N % 128 == 0 && K % 32 == 0 && !(flags & PERO_GEMM_ROWDOT) &&
-                 (g_gemm_policy == 0 || g_gemm_policy == 7 || g_gemm_policy == 10 || g_gemm_policy == 11 || g_gemm_policy == 12 || g_gemm_policy == 20),
+    // bit-mask ReLU gate: only the e256 / r256 epilogues read or write it
+    PERO_REQUIRE(fast && gate && batch == 1 && out_dtype == PERO_BF16 && !ta && !(flags & PERO_GEMM_ATOMIC) && !force128 && M % 256 == 0 &&
+                 N % 128 == 0 && K % 32 == 0 && !(flags & PERO_GEMM_ROWDOT) && (g_gemm_policy == 0 || g_gemm_policy == 7 || g_gemm_policy == 20),
                  "pero_gemm: PERO_GEMM_RELU_BITS needs a bf16 product for the 256-row tile kernels (M %% 256, N %% 128, K %% 32, batch 1)");
   }
   if (fast) {
-    // tile-size / split-K policy.  256x256 tiles halve the L2->LDS bytes per flop; they need ~a CU-count of work
-    // items.  k_split == 0 (with PERO_GEMM_ATOMIC) lets the library choose the split.
     const bool atomic = flags & PERO_GEMM_ATOMIC;
-    const bool can256 = M % 256 == 0 && N % 256 == 0 && !(flags & PERO_GEMM_TILE128);
+    const bool can256 = M % 256 == 0 && N % 256 == 0 && !force128;
     const long long t256 = can256 ? (M / 256) * (N / 256) * batch : 0;
     const long long t128 = (M / T_BM) * (N / T_BN) * batch;
-    // (measured on the step's shapes: with the deferred epilogue the 128-tile kernel is as fast or faster than the
-    //  256-tile one, whose epilogue is not deferred - it would need 256 accumulator VGPRs; 256 tiles stay opt-in)
-    bool use256 = false;
-    (void)t256;
     const int k_split_req = k_split;
-    // split-K weight gradients on the eight-phase 256x256x64 main loop (gemm_e.hip, EP_SPLITK): long k-slices, LDS-staged atomics
-    if (atomic && !forced0 && out_dtype == PERO_F32 && can256 &&
-        (g_gemm_policy == 20 || (g_gemm_policy == 0 && g_gemm_e256_min > 0 && K >= 32768 && t256 >= g_gemm_e_splitk_min)) &&
+    const bool auto_or = g_gemm_policy == 0;
+    // the eight-phase persistent 256x256x64 kernel (gemm_e.hip): split-K weight gradients on long reductions ...
+    if (atomic && out_dtype == PERO_F32 && can256 &&
+        (g_gemm_policy == 20 || (auto_or && (force256 || (g_gemm_e256_min > 0 && K >= 32768 && t256 >= g_gemm_e_splitk_min)))) &&
         pero_launch_gemm_e256(p, batch, k_split_req, ta, tb, true, st, -1)) {
       PERO_CHECK_LAUNCH("pero_gemm(e256 split-K)");
       return PERO_OK;
     }
+    // ... and stored bf16 products with every fused epilogue
+    if (!atomic && can256 && (g_gemm_policy == 20 || (auto_or && (force256 || (g_gemm_e256_min > 0 && t256 >= g_gemm_e256_min)))) &&
+        pero_launch_gemm_e256(pc, batch, k_split, ta, tb, out_dtype == PERO_F32, st, -1)) {
+      *colsum_fused = want_cs;
+      PERO_CHECK_LAUNCH("pero_gemm(e256)");
+      return PERO_OK;
+    }
+    PERO_REQUIRE(!(g_gemm_policy == 20 && (g_gemm_e_var & (8 | 64))), "pero_gemm: the stamp build did not take this product");  // its `gate` is a debug buffer
     if (atomic && k_split == 0) {
       long long ks = (g_splitk_items + t128 - 1) / t128;
       if (ks > K / 512) ks = K / 512;
@@ -502,102 +487,23 @@ static int gemm_dispatch(const void* A, const void* B, void* C, const float* bia
     } else if (k_split < 1) {
       k_split = 1;
     }
-    if (g_gemm_policy == 14 && atomic && !forced0 && out_dtype == PERO_F32 && M % 256 == 0) {  // experiment: 256x128x32 split-K tiles
-      long long ks2 = k_split_req;
-      const long long tr = (M / 256) * (N / 128);
-      if (ks2 == 0) {
-        ks2 = (g_splitk_items + tr - 1) / tr;
-        if (ks2 >= 8) ks2 = ((ks2 + 7) / 8) * 8;
-        else if (ks2 > 4) ks2 = 8;
-        else if (ks2 == 3) ks2 = 4;
-        if (ks2 > K / 256) ks2 = K / 256;
-        if (ks2 < 1) ks2 = 1;
-      }
-      if (pero_launch_gemm_r256(p, batch, (int)ks2, ta, tb, true, st)) {
-        PERO_CHECK_LAUNCH("pero_gemm(r256 split-K)");
-        return PERO_OK;
-      }
+    // split-K atomics: one 128x128x64 tile per workgroup
+    if (!force128 && atomic && g_gemm_policy != 7 && pero_launch_gemm_o128(p, batch, k_split, ta, tb, out_dtype == PERO_F32, st)) {
+      PERO_CHECK_LAUNCH("pero_gemm(bf16 o128)");
+      return PERO_OK;
     }
-    if ((g_gemm_policy == 13 || (g_gemm_policy == 0 && g_splitk_t256_min > 0 && t256 >= g_splitk_t256_min && K >= 131072)) && atomic && can256 && !forced0 &&
-        out_dtype == PERO_F32) {  // 256x256x64 split-K tiles
-      long long ks2 = k_split_req;
-      if (ks2 == 0) {
-        ks2 = 256 / t256;                       // one round of workgroups, slices in multiples of 8 (one per XCD)
-        if (ks2 >= 8) ks2 = (ks2 / 8) * 8;
-        else if (ks2 >= 4) ks2 = 4;
-        else if (ks2 >= 2) ks2 = 2;
-        if (ks2 > K / 256) ks2 = K / 256;
-        if (ks2 < 1) ks2 = 1;
-      }
-      if (pero_launch_gemm_v256(p, batch, (int)ks2, ta, tb, true, st)) {
-        PERO_CHECK_LAUNCH("pero_gemm(v256 split-K)");
-        return PERO_OK;
-      }
-    }
-    if (!forced0 && (g_gemm_policy == 4 || ((g_gemm_policy == 0 || g_gemm_policy >= 7) && atomic)) &&
+    if (!force128 && !atomic && g_gemm_policy == 4 && !want_cs && !(flags & PERO_GEMM_RELU_BITS) &&
         pero_launch_gemm_o128(p, batch, k_split, ta, tb, out_dtype == PERO_F32, st)) {
       PERO_CHECK_LAUNCH("pero_gemm(bf16 o128)");
       return PERO_OK;
     }
-    if (g_gemm_policy == 9 && !forced0 && !atomic && pero_launch_gemm_p128(p, batch, k_split, ta, tb, out_dtype == PERO_F32, st)) {
-      PERO_CHECK_LAUNCH("pero_gemm(bf16 p128)");
-      return PERO_OK;
-    }
-    // the eight-phase persistent 256x256x64 kernel (gemm_e.hip): stored bf16 products with every fused epilogue
-    if ((g_gemm_policy == 20 || (g_gemm_policy == 0 && g_gemm_e256_min > 0 && t256 >= g_gemm_e256_min)) && !forced0 && !atomic &&
-        pero_launch_gemm_e256(pc, batch, k_split, ta, tb, out_dtype == PERO_F32, st, -1)) {
-      *colsum_fused = want_cs;
-      PERO_CHECK_LAUNCH("pero_gemm(e256)");
-      return PERO_OK;
-    }
-    PERO_REQUIRE(!(g_gemm_policy == 20 && (g_gemm_e_var & 8)), "pero_gemm: the stamp build did not take this product");  // its `gate` is a debug buffer
-    if (g_gemm_policy == 15 && !forced0 && !atomic && !want_cs && pero_launch_gemm_x256(p, batch, k_split, ta, tb, out_dtype == PERO_F32, st)) {
-      PERO_CHECK_LAUNCH("pero_gemm(x256)");
-      return PERO_OK;
-    }
-    // w256 carries the fused row-dot epilogue (K-contiguous bf16 products only).  Its column-sum epilogue (EPI 1) is NOT
-    // used: the per-tile atomics sit in the in-order memory queue ahead of the next tile's first stage and the persistent
-    // loop waits for them - linear2's input gradient took 325 us against 232 us with gemm_bf16_v256, whose atomics are the
-    // last thing a workgroup does (tools/dx_epi_bench.py).
-    const bool w_fuse = want_rd && !ta && !tb && out_dtype != PERO_F32;
-    if ((g_gemm_policy == 12 || (g_gemm_policy == 0 && g_gemm_persistent && (flags & PERO_GEMM_TILE_V) && t256 >= 192 && (!want_cs || w_fuse))) && !forced0 && !atomic && pero_launch_gemm_w256(w_fuse ? pc : p, batch, k_split, ta, tb, out_dtype == PERO_F32, st)) {
-      *colsum_fused = w_fuse;
-      PERO_CHECK_LAUNCH("pero_gemm(w256)");
-      return PERO_OK;
-    }
-    if ((g_gemm_policy == 10 || g_gemm_policy == 12 || (g_gemm_policy == 11 && K >= 1024) || (g_gemm_policy == 0 && (flags & PERO_GEMM_TILE_V) && t256 >= 192)) && !forced0 && !atomic && !want_rd && pero_launch_gemm_v256(want_cs ? pc : p, batch, k_split, ta, tb, out_dtype == PERO_F32, st)) {
-      *colsum_fused = want_cs;
-      PERO_CHECK_LAUNCH("pero_gemm(v256)");
-      return PERO_OK;
-    }
-    if (g_gemm_policy == 8 && !forced0 && !atomic && pero_launch_gemm_q256(p, batch, k_split, ta, tb, out_dtype == PERO_F32, st)) {
-      PERO_CHECK_LAUNCH("pero_gemm(bf16 q256)");
-      return PERO_OK;
-    }
-    // (a bit-mask gate that the 256x256 kernels above declined always ends here, whatever the policy: only these epilogues know it)
-    if ((g_gemm_policy == 7 || g_gemm_policy == 0 || g_gemm_policy == 11 || g_gemm_policy == 15 || (flags & PERO_GEMM_RELU_BITS)) && !forced0 && !atomic && pero_launch_gemm_r256(want_cs ? pc : p, batch, k_split, ta, tb, out_dtype == PERO_F32, st)) {
+    // 256x128x32 tiles, two workgroups per CU: stored products of small batches; carries the column-sum / row-dot / bit-mask epilogues
+    if (!force128 && !atomic && g_gemm_policy != 4 && pero_launch_gemm_r256(want_cs ? pc : p, batch, k_split, ta, tb, out_dtype == PERO_F32, st)) {
       *colsum_fused = want_cs;
       PERO_CHECK_LAUNCH("pero_gemm(bf16 r256)");
       return PERO_OK;
     }
     PERO_REQUIRE(!(flags & PERO_GEMM_RELU_BITS), "pero_gemm: no kernel took the PERO_GEMM_RELU_BITS product (internal)");
-    if (flags & PERO_GEMM_TILE256) use256 = can256;
-    // default for non-atomic products (measured, M = 32768): the four-workgroups-per-CU 128x128x32 kernel wins on
-    // every shape of the step except long-K products with a small output (K >= 2048), where the 256 tile wins
-    const bool forced = flags & (PERO_GEMM_TILE128 | PERO_GEMM_TILE256 | PERO_GEMM_TILE_S);
-    if (!forced && !atomic) {
-      if (K >= 2048 && t256 >= 192 && !tb) use256 = true;
-    }
-    if (g_gemm_policy == 0 || g_gemm_policy >= 7) use256 = (flags & PERO_GEMM_TILE256) && can256;
-    if (((flags & PERO_GEMM_TILE_S) || (!forced && !use256)) && !atomic &&
-        pero_launch_gemm_s128(p, batch, k_split, ta, tb, out_dtype == PERO_F32, st)) {
-      PERO_CHECK_LAUNCH("pero_gemm(bf16 s128)");
-      return PERO_OK;
-    }
-    if (use256 && pero_launch_gemm_t256(p, batch, k_split, ta, tb, out_dtype == PERO_F32, st)) {
-      PERO_CHECK_LAUNCH("pero_gemm(bf16 256-tile)");
-      return PERO_OK;
-    }
     if (k_split > 1) {
 
       long long steps = K / T_BK;

@@ -1,4 +1,4 @@
-// Shared by the bf16 tile GEMM kernels (gemm.hip: 128x128 tiles, gemm256.hip: 256x256 tiles).
+// Shared by the bf16 tile GEMM kernels (gemm.hip, gemm_o.hip, gemm_r.hip, gemm_e.hip).
 #pragma once
 #include "common.hpp"
 
@@ -26,23 +26,9 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("" ::: "memory");  // keep later LDS accesses below the barrier
 }
 
-// host entry of the 256x256 kernel (gemm256.hip); returns false when the shape does not qualify
-bool pero_launch_gemm_t256(const GemmP& p, long long batch, int k_split, bool ta, bool tb, bool out_f32, hipStream_t st);
-// host entry of the occupancy-tuned 128x128x32 kernel (gemm_s.hip)
-bool pero_launch_gemm_s128(const GemmP& p, long long batch, int k_split, bool ta, bool tb, bool out_f32, hipStream_t st);
-// host entry of the simple one-tile-per-workgroup 128x128x64 kernel (gemm_o.hip)
+// host entry of the one-tile-per-workgroup 128x128x64 kernel (gemm_o.hip): split-K weight gradients of short reductions
 bool pero_launch_gemm_o128(const GemmP& p, long long batch, int k_split, bool ta, bool tb, bool out_f32, hipStream_t st);
-// host entry of the 256x128x32 eight-wave kernel (gemm_r.hip)
+// host entry of the 256x128x32 eight-wave kernel (gemm_r.hip): stored products of small batches
 bool pero_launch_gemm_r256(const GemmP& p, long long batch, int k_split, bool ta, bool tb, bool out_f32, hipStream_t st);
-// host entry of the 256x256x32 sixteen-wave kernel (gemm_q.hip)
-bool pero_launch_gemm_q256(const GemmP& p, long long batch, int k_split, bool ta, bool tb, bool out_f32, hipStream_t st);
-// host entry of the 256x256x64 sixteen-wave kernel (gemm_v.hip): whole 128-byte row segments per LDS-DMA lane group
-bool pero_launch_gemm_v256(const GemmP& p, long long batch, int k_split, bool ta, bool tb, bool out_f32, hipStream_t st);
-// host entry of the experimental four-wave 256x256x64 kernel (gemm_x.hip; NT products only)
-bool pero_launch_gemm_x256(const GemmP& p, long long batch, int k_split, bool ta, bool tb, bool out_f32, hipStream_t st);
-// host entry of the persistent 256x256x64 kernel (gemm_w.hip): epilogue overlapped with the next tile's main loop
-bool pero_launch_gemm_w256(const GemmP& p, long long batch, int k_split, bool ta, bool tb, bool out_f32, hipStream_t st);
-// host entry of the software-pipelined 128x128x32 kernel (gemm_p.hip)
-bool pero_launch_gemm_p128(const GemmP& p, long long batch, int k_split, bool ta, bool tb, bool out_f32, hipStream_t st);
-// host entry of the eight-phase ping-pong persistent 256x256x64 kernel (gemm_e.hip)
+// host entry of the eight-phase ping-pong persistent 256x256x64 kernel (gemm_e.hip); var < 0: the "gemm_e_var" option
 bool pero_launch_gemm_e256(const GemmP& p, long long batch, int k_split, bool ta, bool tb, bool out_f32, hipStream_t st, int var = 0);

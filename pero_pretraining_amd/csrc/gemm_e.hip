@@ -404,7 +404,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p, int ks) {
           const int col = 64 * seg + lane;
           const float v = *(const float*)(smem + row * 1024 + ((((col >> 2)) ^ (row & 15)) << 4) + (col & 3) * 4);
           const long long grow = tm0 + 128 * (row >> 6) + 64 * ha + (row & 63);
-          atomicAdd(C + grow * p.ldc + tn0 + col, v);
+          atomicAdd(C + grow * p.ldc + tn0 + col, v * p.alpha);
         }
       }
       return;
@@ -585,7 +585,7 @@ bool pero_launch_gemm_e256(const GemmP& p0, long long batch, int k_split, bool t
   int ks = 0;
   if (p0.flags & PERO_GEMM_ATOMIC) {
     // split-K: f32 C, plain product, equal slices of whole K-tiles, one slice set per XCD
-    if (!out_f32 || p0.alpha != 1.0f || p0.bias || p0.resid || (p0.gate && !(var & 64)) || (p0.flags & ~(PERO_GEMM_ATOMIC | PERO_GEMM_TRANS_A | PERO_GEMM_TRANS_B | PERO_GEMM_TILE_V))) return false;
+    if (!out_f32 || p0.bias || p0.resid || (p0.gate && !(var & 64)) || (p0.flags & ~(PERO_GEMM_ATOMIC | PERO_GEMM_TRANS_A | PERO_GEMM_TRANS_B | PERO_GEMM_TILE_V | PERO_GEMM_TILE256))) return false;
     const long long tiles = (p0.M / E_BM) * (p0.N / E_BN), steps = p0.K / E_BK;
     ks = k_split;
     if (ks <= 0) {  // the library chooses: one round of workgroups over the CUs

@@ -14,7 +14,7 @@ import math
 import torch
 
 from . import lowp, ops
-from ._lib import GEMM_ATOMIC, GEMM_TILE_V, GEMM_TRANS_A, GEMM_TRANS_B
+from ._lib import GEMM_ATOMIC, GEMM_TRANS_A, GEMM_TRANS_B
 
 LN_EPS = 1e-5
 
@@ -33,10 +33,10 @@ def ensure_grad(p):
     return p.grad
 
 
-FWD_TILE_FLAGS = GEMM_TILE_V
+FWD_TILE_FLAGS = 0
 FUSE_B1_COLSUM = True    # linear1's bias gradient from the epilogue of linear2's input-gradient product (else: a column-sum pass on the side stream)
 DX_ON_WT = True          # input gradients on transposed weight copies (lowp.weight_t)
-DX_TILE_FLAGS = GEMM_TILE_V
+DX_TILE_FLAGS = 0
 RELU_GATE_BITS = True    # linear1's ReLU leaves a bit mask (free in its epilogue); linear2's input gradient reads a byte per 8 columns, all of a
                          # tile's bytes ahead of the staging barriers, instead of eight dependent 16-byte gate rows: step -0.7 %
 

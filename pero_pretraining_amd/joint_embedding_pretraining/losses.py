@@ -5,7 +5,7 @@ import torch
 import torch.distributed as dist
 
 from .. import ops
-from .._lib import GEMM_TILE_V, GEMM_TRANS_A, GEMM_TRANS_B
+from .._lib import GEMM_TRANS_A, GEMM_TRANS_B
 from ..precision import compute_dtype
 
 
@@ -55,8 +55,12 @@ class _VICRegFn(torch.autograd.Function):
             cs, inv = pack[:D] * (m_loc / m), pack[D:].clone()
         zc, sumsq = ops.center_cols(z, cs.contiguous(), m_loc)
         # rows centred with the global mean: sum over ranks of zc^T zc IS the global scatter matrix
-        cov = ops.gemm(zc, zc, trans_a=True, trans_b=True, alpha=1.0 / (m - 1), out_dtype=torch.float32,
-                       extra_flags=GEMM_TILE_V)  # the loss products run alone on the GPU: 256x256x64 tiles
+        if dtype == torch.bfloat16:
+            # the D x D SYRK as a split-K product into a zeroed f32 matrix: the long-reduction mode of the 256x256x64 kernel
+            cov = torch.zeros((D, D), device=x2.device, dtype=torch.float32)
+            ops.gemm(zc, zc, out=cov, trans_a=True, trans_b=True, alpha=1.0 / (m - 1), atomic=True, k_split=0)
+        else:
+            cov = ops.gemm(zc, zc, trans_a=True, trans_b=True, alpha=1.0 / (m - 1), out_dtype=torch.float32)
         if group is not None:
             # exchange 2: the D x D scatter matrix (f32: 64 MiB at D = 4096) and the D squared column norms
             dist.all_reduce(cov, group=group)
@@ -77,7 +81,7 @@ class _VICRegFn(torch.autograd.Function):
         # global statistics: every rank holds the SAME loss and differentiates it w.r.t. its own rows; the data-parallel
         # gradient AVERAGE over ranks would divide the sum of those parts by world, so the seed is multiplied by world
         gdev = g.detach().reshape(1).to(torch.float32) * ctx.seed
-        dzc = ops.gemm(zc, G, extra_flags=GEMM_TILE_V)  # (m_pad, D): d(wv*var + wc*cov)/d zc
+        dzc = ops.gemm(zc, G)  # (m_pad, D): d(wv*var + wc*cov)/d zc
         dx = torch.zeros_like(x2)
         dy = torch.zeros_like(y2)
         ops.scatter_add_rows_scaled(dzc[:n1], jx, dx, gdev)

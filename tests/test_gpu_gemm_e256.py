@@ -1,0 +1,120 @@
+"""The eight-phase persistent 256x256x64 bf16 GEMM (csrc/gemm_e.hip) against exact / f32 references and against the other
+tile kernels (bit for bit): every operand layout, every fused epilogue, the split-K mode, many tiles per workgroup."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def e256():
+    from pero_pretraining_amd import _lib, ops
+    lib = _lib.lib()
+    lib.pero_set_option(b"gemm_policy", 20)
+    yield ops
+    lib.pero_set_option(b"gemm_policy", 0)
+
+
+def _setpol(p):
+    from pero_pretraining_amd import _lib
+    _lib.lib().pero_set_option(b"gemm_policy", p)
+
+
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("K", [128, 192, 512])
+def test_layouts_exact_integers(e256, ta, tb, K):
+    """small integers: every partial sum is exact in f32 and the bf16 result is exact - any wrong fragment, tile or k-slice shows."""
+    M, N = 768, 512
+    g = torch.Generator().manual_seed(11 + K)
+    a = torch.randint(-3, 4, (K, M) if ta else (M, K), generator=g).float()
+    b = torch.randint(-3, 4, (K, N) if tb else (N, K), generator=g).float()
+    ref = (a.t() if ta else a) @ (b.t() if tb else b).t()
+    out = e256.gemm(a.cuda().bfloat16(), b.cuda().bfloat16(), trans_a=ta, trans_b=tb)
+    assert torch.equal(out.float().cpu(), ref.bfloat16().float())
+
+
+@pytest.mark.parametrize("M,N,K", [(1024, 512, 512), (1024, 1536, 192), (2048, 256, 128)])
+def test_epilogues_match_the_other_tile_kernel_bit_for_bit(e256, M, N, K):
+    """bias / ReLU / residual / bit mask out and in / column sums / row dots: same bytes as gemm_bf16_r256 (policy 7), whose
+    epilogue is the f32 acc * alpha + bias (+ residual) -> one rounding that every tile kernel of the library implements."""
+    ops = e256
+    torch.manual_seed(M + N + K)
+    x = (torch.randn(M, K, device="cuda") * 0.5).bfloat16()
+    w = (torch.randn(N, K, device="cuda") * 0.5).bfloat16()
+    bias = torch.randn(N, device="cuda")
+    res = torch.randn(M, N, device="cuda").bfloat16()
+
+    def both(fn):
+        _setpol(20)
+        a = fn()
+        _setpol(7)
+        b = fn()
+        _setpol(20)
+        return a, b
+
+    for kw in ({}, {"bias": bias}, {"bias": bias, "relu": True}, {"bias": bias, "residual": res}, {"residual": res}):
+        a, b = both(lambda: ops.gemm(x, w, **kw))
+        assert torch.equal(a, b), kw
+    ref = x.float() @ w.float().t()
+    y = ops.gemm(x, w, bias=bias, residual=res)
+    assert float((y.float() - (ref + bias + res.float())).abs().max()) <= 2e-2 * float(ref.abs().max())
+    # ReLU bit mask out
+    bits = torch.zeros((M, N // 8), device="cuda", dtype=torch.uint8)
+    h = ops.gemm(x, w, bias=bias, relu=True, relu_bits=bits)
+    assert torch.equal(h, ops.gemm(x, w, bias=bias, relu=True))
+    want = np.packbits((h.float() > 0).cpu().numpy(), axis=1, bitorder="little")
+    assert np.array_equal(bits.cpu().numpy(), want)
+    # ... in, with and without the fused column sums
+    cs = torch.full((N,), 3.0, device="cuda")
+    gd = ops.gemm(x, w, relu_bits=bits, colsum_into=cs)
+    _setpol(7)
+    gr = ops.gemm(x, w, gate=h)
+    _setpol(20)
+    assert torch.equal(gd, gr) and torch.equal(gd, ops.gemm(x, w, relu_bits=bits))
+    want_cs = 3.0 + gd.float().sum(0)
+    assert float((cs - want_cs).abs().max()) <= 1e-3 * max(1.0, float(want_cs.abs().max()))
+    # row dots
+    if N % 128 == 0:
+        dots = torch.full((M, N // 128), 7.0, device="cuda")
+        yd = ops.gemm(x, w, rowdot=(res, dots))
+        assert torch.equal(yd, ops.gemm(x, w))
+        dref = (yd.float() * res.float()).view(M, N // 128, 128).sum(-1)
+        assert float((dots - dref).abs().max()) <= 1e-3 * max(1.0, float(dref.abs().max()))
+
+
+def test_many_tiles_per_workgroup_and_repeatability(e256):
+    """3072 tiles over 256 persistent workgroups (the cross-tile LDS-DMA stream, the counted waits past the previous epilogue's
+    stores); ten launches give identical bytes (a missed wait shows as run-to-run differences)."""
+    ops = e256
+    torch.manual_seed(5)
+    x = (torch.randn(131072, 512, device="cuda") * 0.5).bfloat16()
+    w = (torch.randn(1536, 512, device="cuda") * 0.5).bfloat16()
+    res = torch.randn(131072, 1536, device="cuda").bfloat16()
+    for kw in ({}, {"residual": res}):
+        y0 = ops.gemm(x, w, **kw)
+        for sl in (slice(0, 2048), slice(65536 - 1024, 65536 + 1024), slice(131072 - 2048, 131072)):
+            ref = x[sl].float() @ w.float().t() + (res[sl].float() if kw else 0)
+            assert float((y0[sl].float() - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
+        for _ in range(10):
+            assert torch.equal(ops.gemm(x, w, **kw), y0)
+        _setpol(7)
+        assert torch.equal(ops.gemm(x[:4096], w, **({"residual": res[:4096]} if kw else {})), y0[:4096])
+        _setpol(20)
+
+
+@pytest.mark.parametrize("N,K,rows", [(512, 512, 8192), (1536, 512, 65536), (768, 256, 16384)])
+def test_split_k_weight_gradient_mode(e256, N, K, rows):
+    """TT split-K (f32 atomics through the LDS-staged epilogue): XCD-aligned and plain slice counts, uneven slices, alpha."""
+    ops = e256
+    g = torch.Generator(device="cuda").manual_seed(N + K)
+    dy = (torch.randn(rows, N, device="cuda", generator=g) * 0.5).bfloat16()
+    x = (torch.randn(rows, K, device="cuda", generator=g) * 0.5).bfloat16()
+    ref = dy[:, :].double().t() @ x.double()
+    for ks in (0, 1, 3, 8):
+        c = torch.zeros(N, K, device="cuda")
+        ops.gemm(dy, x, out=c, trans_a=True, trans_b=True, atomic=True, k_split=ks)
+        assert float((c.double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) * max(1, rows // 8192), ks
+    c = torch.ones(N, K, device="cuda")
+    ops.gemm(dy, x, out=c, trans_a=True, trans_b=True, atomic=True, k_split=0, alpha=0.5)
+    assert float((c.double() - (1.0 + 0.5 * ref)).abs().max()) <= 1e-5 * float(ref.abs().max()) * max(1, rows // 8192)

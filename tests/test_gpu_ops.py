@@ -105,7 +105,8 @@ def test_gemm_bf16_fast_epilogues_and_splitk(ops):
 @pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
 @pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
 def test_gemm_bf16_tile256_layouts_exact_integers(ops, ta, tb, out_dtype):
-    """256x256-tile kernel, forced: all operand layouts, several tiles per persistent workgroup, exact integers."""
+    """PERO_GEMM_TILE256 (the eight-phase 256x256x64 kernel for bf16 outputs; f32 outputs fall through to the other tile
+    kernels): all operand layouts, an odd number of K-tiles, exact integers."""
     from pero_pretraining_amd._lib import GEMM_TILE256
     M, N, K = 512, 768, 320
     g = torch.Generator().manual_seed(11)
@@ -118,32 +119,32 @@ def test_gemm_bf16_tile256_layouts_exact_integers(ops, ta, tb, out_dtype):
 
 
 @pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
-def test_gemm_bf16_s128_layouts_and_epilogues(ops, ta, tb):
-    """128x128x32 high-occupancy kernel, forced: exact integers in all layouts + the fused epilogue."""
-    M, N, K = 384, 256, 160
+def test_gemm_bf16_t128_layouts_and_epilogues(ops, ta, tb):
+    """persistent 128x128x64 kernel, forced (PERO_GEMM_TILE128): exact integers in all layouts + the fused epilogue."""
+    M, N, K = 384, 256, 192
     g = torch.Generator().manual_seed(13)
     a = torch.randint(-3, 4, (K, M) if ta else (M, K), generator=g).float()
     b = torch.randint(-3, 4, (K, N) if tb else (N, K), generator=g).float()
     ref = (a.t() if ta else a) @ (b.t() if tb else b).t()
     for od in (torch.bfloat16, torch.float32):
-        out = ops.gemm(dev(a, torch.bfloat16), dev(b, torch.bfloat16), trans_a=ta, trans_b=tb, out_dtype=od, extra_flags=256)
+        out = ops.gemm(dev(a, torch.bfloat16), dev(b, torch.bfloat16), trans_a=ta, trans_b=tb, out_dtype=od, extra_flags=64)
         assert torch.equal(out.float().cpu(), ref.to(od).float())
     bias = torch.randn(N, generator=g)
     res = torch.randn(M, N, generator=g).bfloat16()
     gate = torch.randn(M, N, generator=g).bfloat16()
     full = torch.relu(0.5 * ref.double() + bias.double() + res.double()) * (gate.double() > 0)
     out = ops.gemm(dev(a, torch.bfloat16), dev(b, torch.bfloat16), trans_a=ta, trans_b=tb, bias=dev(bias), residual=dev(res),
-                   gate=dev(gate), relu=True, alpha=0.5, extra_flags=256)
+                   gate=dev(gate), relu=True, alpha=0.5, extra_flags=64)
     assert rel_err(out, full) < 2 ** -8
 
 
 @pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
-@pytest.mark.parametrize("policy", [7, 8, 9])
-def test_gemm_bf16_r256_layouts_and_epilogues(ops, ta, tb, policy):
-    """256x128x32 eight-wave (policy 7) and 256x256x32 sixteen-wave (policy 8) kernels: exact integers in all
+@pytest.mark.parametrize("policy", [7, 4])
+def test_gemm_bf16_r256_o128_layouts_and_epilogues(ops, ta, tb, policy):
+    """256x128x32 eight-wave (policy 7) and one-tile-per-workgroup 128x128x64 (policy 4) kernels: exact integers in all
     layouts + the fused epilogue."""
     from pero_pretraining_amd import _lib
-    M, N, K = 768, 512, 160
+    M, N, K = 768, 512, 192
     g = torch.Generator().manual_seed(14)
     a = torch.randint(-3, 4, (K, M) if ta else (M, K), generator=g).float()
     b = torch.randint(-3, 4, (K, N) if tb else (N, K), generator=g).float()
@@ -540,7 +541,7 @@ def test_transpose_multi_and_transposed_weight_copies():
 @pytest.mark.parametrize("M,N,K", [(512, 256, 192), (256, 128, 64), (1024, 2048, 512)])
 def test_gemm_relu_gate_as_bit_mask(M, N, K):
     """PERO_GEMM_RELU_BITS: the ReLU product leaves bit (n & 7) of byte [m][n / 8] = (stored value > 0); the gated product
-    reads that mask instead of the bf16 activation - same bytes out as with the bf16 gate (w256 / v256 / r256 epilogues)."""
+    reads that mask instead of the bf16 activation - same bytes out as with the bf16 gate (e256 / r256 epilogues)."""
     from pero_pretraining_amd import _lib, ops
     torch.manual_seed(M + N)
     x = (torch.randn(M, K, device="cuda") * 0.5).to(torch.bfloat16)
@@ -548,8 +549,8 @@ def test_gemm_relu_gate_as_bit_mask(M, N, K):
     b = torch.randn(N, device="cuda")
     dy = (torch.randn(M, K, device="cuda") * 0.5).to(torch.bfloat16)
     wt = (torch.randn(N, K, device="cuda") * 0.2).to(torch.bfloat16)  # (in = N, out = K) transposed copy of the next weight
-    # (policy 12 sends every stored product to the persistent w256 kernel, whatever the tile count: its epilogue mode 3)
-    for tile_flags, policy in ((0, 0), (_lib.GEMM_TILE_V, 0), (_lib.GEMM_TILE_V, 12), (_lib.GEMM_TILE_V, 10)):
+    # (policy 20 sends every stored product to the eight-phase kernel whatever the tile count, policy 7 to the 256x128x32 one)
+    for tile_flags, policy in ((0, 0), (0, 7), (0, 20)):
         _lib.lib().pero_set_option(b"gemm_policy", policy)
         bits = torch.zeros((M, N // 8), device="cuda", dtype=torch.uint8)
         h = ops.gemm(x, w, bias=b, relu=True, relu_bits=bits, extra_flags=tile_flags)
@@ -562,8 +563,11 @@ def test_gemm_relu_gate_as_bit_mask(M, N, K):
             got = ops.gemm(dy, wt, relu_bits=bits, extra_flags=tile_flags, **kw_a)
             ref = ops.gemm(dy, wt, gate=h, extra_flags=tile_flags, **kw_b)
             assert torch.equal(got, ref)
-        # (fused column sums add the f32 values, the fall-back pass the stored bf16 ones: which one runs depends on the policy)
-        assert torch.allclose(cs_a, cs_b, rtol=5e-3, atol=5e-2)
+        # (some epilogues add the f32 values before the rounding, others - and the fall-back pass - the stored bf16 ones: which
+        #  one runs depends on the policy; both are within the rounding of the stored result of its exact column sums)
+        want_cs = got.float().sum(0)
+        tol = 4e-3 * float(got.float().abs().sum(0).max())
+        assert float((cs_a - want_cs).abs().max()) <= tol and float((cs_b - want_cs).abs().max()) <= tol
         _lib.lib().pero_set_option(b"gemm_policy", 0)
         ref32 = torch.relu(x.float() @ w.float().t() + b)
         assert float((h.float() - ref32).abs().max()) <= 2e-2 * float(ref32.abs().max())  # (bias and ReLU are in it)

@@ -10,7 +10,7 @@ from pero_pretraining_amd import ops, _lib
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 M = int(args[0]) if args else 65536
 check_only = "--check-only" in sys.argv
-pols = [12, 100]
+pols = [7, 100]
 for a in sys.argv[1:]:
     if a.startswith("--pols"):
         pols = [int(x) for x in a.split("=")[1].split(",")]
@@ -88,11 +88,11 @@ for (N, K) in [(512, 512), (1536, 512), (512, 2048), (256, 128), (768, 192)]:
     fails += check(f"TN {Mc}x{N}x{K}", ops.gemm(xt, w, trans_a=True), ref)
     fails += check(f"TT {Mc}x{N}x{K}", ops.gemm(xt, wt, trans_a=True, trans_b=True), ref)
     # bit-equality with the round-1 kernel (same k order inside a 64-deep K-tile? not required - report only)
-    setpol(12)
+    setpol(7)
     y12 = ops.gemm(x, w, bias=bias)
     setpol(100)
     y20 = ops.gemm(x, w, bias=bias)
-    print(f"  vs policy 12: {int((y12 != y20).sum())} of {y12.numel()} outputs differ", flush=True)
+    print(f"  vs policy 7 (r256): {int((y12 != y20).sum())} of {y12.numel()} outputs differ", flush=True)
 # many tiles per workgroup + repeated launches (races show as run-to-run differences)
 x = (torch.randn(131072, 512, device="cuda") * 0.5).bfloat16()
 w = (torch.randn(1536, 512, device="cuda") * 0.5).bfloat16()
