@@ -47,8 +47,8 @@ class PositionalEncoding(torch.nn.Module):
 
     def draw_offsets(self, batch_size, seq_len, device):
         """Per-line start rows into the table (None = 0 for every line), reference lines 178-188."""
-        if self._next_offsets is not None:
-            off, self._next_offsets = self._next_offsets, None
+        if self._next_offsets:
+            off = self._next_offsets.pop(0)
             return torch.as_tensor(off, dtype=torch.int64).to(device)
         if self.random_shift and self.training:
             max_shift = self.max_len - seq_len
@@ -121,9 +121,10 @@ class TransformerEncoder(ABC, torch.nn.Module):
             self._mask_tile = self._mask_tile.to(device)
         return self._mask_tile
 
-    def set_offsets(self, offsets):
-        """Inject the positional start rows used by the next forward (deterministic parity tests)."""
-        self.position_model._next_offsets = offsets
+    def set_offsets(self, *offsets):
+        """Inject the positional start rows of the next encode(s), one array per encode in call order (the joint step makes
+        two): deterministic parity tests replay the reference's torch.randint draws this way."""
+        self.position_model._next_offsets = [o for o in offsets if o is not None]
 
     @property
     def _param_list(self):

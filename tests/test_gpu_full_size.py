@@ -217,3 +217,103 @@ def test_bench_scale_joint_step_equals_its_sub_batches():
     for k, want in acc.items():
         rel_l2 = float((g_full[k] - want).norm() / want.norm().clamp_min(1e-12))
         assert rel_l2 <= 3e-2, (k, rel_l2)
+
+
+def test_config2_f32_parity_mode_one_line_against_the_oracle(cfg2):
+    """The f32 parity mode at config-2 size (12 layers, d = 512, S = 256: exact-f32 generic GEMM, unfused attention + softmax):
+    one line's logits and loss against the CPU oracle at the 1e-4 bar of north_star."""
+    model, images, labels, mask = cfg2
+    model.eval()
+    m1 = mask[:1].clone()
+    m1[0, 0] = 1
+    with torch.no_grad():
+        res = model(images[:1], labels[:1], m1)            # no autocast: PERO_F32
+    assert res["output"].dtype == torch.float32
+    sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    ref, ref_loss = O.masked_model_forward(sd, O.prepare_images(images[:1].cpu()), labels[:1].cpu(), m1.cpu(), num_heads=4)
+    out = res["output"].cpu()
+    assert float((out - ref).abs().max()) < 1e-4 * max(1.0, float(ref.abs().max()))
+    assert abs(float(res["loss"]) - float(ref_loss)) < 1e-4 * float(ref_loss)
+
+
+def test_config3_masked_model_with_8192_way_head():
+    """BASELINE.json configs[2]: the masked ViT fed by an 8192-code tokenizer (V = K = 8192).  bf16 step on 16 lines: the loss is
+    the masked mean cross entropy of the returned logits (oracle restatement), lines are independent bit for bit, d loss / d
+    logits rows sum to zero (head bias gradient), labels come from the codebook argmin of synthetic encoder features."""
+    import pero_pretraining_amd as P
+    from pero_pretraining_amd import ops
+    from pero_pretraining_amd.masked_pretraining import model as M
+    torch.manual_seed(1)
+    model = M.MaskedTransformerEncoder(M.init_backbone(dict(CFG2_BB)), M.init_head({"in_features": 512, "out_features": 8192})).cuda()
+    rng = np.random.default_rng(33)
+    B = 16
+    images = torch.from_numpy(rng.integers(0, 256, (B, 40, 2048, 3), dtype=np.uint8)).cuda()
+    g = torch.Generator(device="cuda").manual_seed(7)
+    codebook = torch.randn(8192, 512, device="cuda", generator=g)
+    feats = torch.randn(B * 256, 512, device="cuda", generator=g)
+    labels = ops.vq_argmin(feats, codebook).view(B, 256)            # the tokenizer's labels (a11): int64 in [0, 8192)
+    assert labels.dtype == torch.int64 and int(labels.min()) >= 0 and int(labels.max()) < 8192 and len(torch.unique(labels)) > 1000
+    mask = torch.from_numpy((rng.random((B, 256)) < 0.15).astype(np.int64)).cuda()
+    model.train()
+    model.zero_grad()
+    model.backbone.set_offsets(rng.integers(0, 4096 - 256, B))
+    with P.autocast(True):
+        res = model(images, labels, mask)
+    assert res["output"].shape == (B, 256, 8192)
+    want = O.masked_cross_entropy(res["output"].float().cpu(), labels.cpu(), mask.cpu())
+    assert abs(float(res["loss"]) - float(want)) < 1e-4 * float(want)
+    assert abs(float(res["loss"]) - np.log(8192)) < 0.5              # random weights: ~ uniform over the 8192 codes
+    res["loss"].backward()
+    hb = model.head.linear.bias.grad.float()
+    assert torch.isfinite(hb).all() and abs(float(hb.sum())) < 2e-3 * float(hb.abs().sum())
+    model.eval()
+    with torch.no_grad(), P.autocast(True):
+        full = model(images, labels, mask)["output"]
+        assert torch.equal(model(images[5:6], labels[5:6], mask[5:6])["output"][0], full[5])
+
+
+def test_config4_vicreg_at_d4096_bf16_syrk_against_f32_mode_and_oracle():
+    """BASELINE.json configs[3]'s loss at its real width: D = 4096 head outputs, 8448 valid rows (M >= 8192) - the bf16 SYRK / its
+    backward on the split-K 256x256x64 kernel against (i) the f32-mode HIP path on the same rows and (ii) the f64 CPU oracle on a
+    row subset small enough for the CPU (the loss is a function of row statistics: the subset is its own, smaller problem)."""
+    import pero_pretraining_amd as P
+    from pero_pretraining_amd.joint_embedding_pretraining.losses import VICRegLoss
+    rng = np.random.default_rng(4)
+    n, s, d = 18, 256, 4096
+    base = rng.standard_normal((n, s, 64)).astype(np.float32)
+    mix = (rng.standard_normal((64, d)) / 8).astype(np.float32)
+    x = (base @ mix + 0.5 * rng.standard_normal((n, s, d))).astype(np.float32)     # correlated columns: a covariance term that matters
+    y = (x + 0.3 * rng.standard_normal((n, s, d))).astype(np.float32)
+    im = np.ones((n, s), np.uint8)
+    im[:, :14] = 0
+    im[:, -10:] = 0                                                                  # 232 valid columns per line and view: 2 * 18 * 232 = 8352 rows
+    sm = np.ones((n, s), np.uint8)
+    sm[:, :20] = 0
+    sm2 = sm[:, ::-1].copy()
+    xb, yb = torch.from_numpy(x).bfloat16(), torch.from_numpy(y).bfloat16()
+    assert 2 * int(im.sum()) >= 8192
+    masks = [torch.from_numpy(m).cuda() for m in (im, im, sm, sm2)]
+    # (i) bf16 path vs f32-mode HIP path on the same (bf16-rounded) inputs
+    xg, yg = xb.cuda().requires_grad_(True), yb.cuda().requires_grad_(True)
+    with P.autocast(True):
+        res = VICRegLoss()(xg, yg, *masks)
+    res["loss"].backward()
+    xf, yf = xb.float().cuda().requires_grad_(True), yb.float().cuda().requires_grad_(True)
+    ref = VICRegLoss()(xf, yf, *masks)
+    ref["loss"].backward()
+    for k in ("loss", "loss.variance", "loss.invariance", "loss.covariance"):
+        assert abs(float(res[k]) - float(ref[k])) < 1e-2 * abs(float(ref[k])) + 1e-6, (k, float(res[k]), float(ref[k]))
+    gx, gr = xg.grad.float().flatten().double(), xf.grad.flatten().double()
+    assert float(gx @ gr / (gx.norm() * gr.norm())) > 0.995
+    assert abs(float(gx.norm() / gr.norm()) - 1.0) < 2e-2
+    # (ii) a 2-line subset (928 rows) through the f64 oracle vs both HIP modes
+    sub = slice(0, 2)
+    xo, yo = xb[sub].double().requires_grad_(True), yb[sub].double().requires_grad_(True)
+    oref = O.vicreg_loss(xo, yo, im[sub], im[sub], sm[sub], sm2[sub])
+    ms = [m[sub].contiguous() for m in masks]
+    f32 = VICRegLoss()(xb[sub].float().cuda(), yb[sub].float().cuda(), *ms)
+    with P.autocast(True):
+        b16 = VICRegLoss()(xb[sub].cuda(), yb[sub].cuda(), *ms)
+    for k in ("loss", "loss.variance", "loss.invariance", "loss.covariance"):
+        assert abs(float(f32[k]) - float(oref[k])) < 1e-4 * abs(float(oref[k])) + 1e-7, (k, float(f32[k]), float(oref[k]))
+        assert abs(float(b16[k]) - float(oref[k])) < 2e-2 * abs(float(oref[k])) + 1e-6, (k, float(b16[k]), float(oref[k]))
