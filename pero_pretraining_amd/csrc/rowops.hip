@@ -395,6 +395,12 @@ __global__ __launch_bounds__(256) void ce_rows_k(const T* logits, const int64_t*
     if (tid == 0) { work[row] = 0.f; work[rows + 8 + row] = 0.f; }
     return;
   }
+  if (lab < 0 || lab >= V) {
+    // a participating row whose label is outside [0, V) (masked_pretraining/model.py:82: F.cross_entropy raises there): the
+    // loss becomes NaN instead of reading logits out of bounds - loud, no device fault
+    if (tid == 0) { work[row] = __builtin_nanf(""); work[rows + 8 + row] = 0.f; }
+    return;
+  }
   const T* lr = logits + row * V;
   if (V == 4096 && (((uintptr_t)lr) & 15) == 0) {
     // the whole row in registers (2 x 8 values per thread): one pass over memory, one barrier pair
@@ -458,6 +464,7 @@ __global__ __launch_bounds__(256) void ce_bwd_k(const T* logits, const int64_t* 
                         // blocks (or a grid-stride loop) reached only 2.7 TB/s
 
   if (dloss) w *= dloss[0];
+  if (lab < 0 || lab >= V) w = __builtin_nanf("");  // out-of-range label on a participating row: NaN gradient row (see ce_rows_k)
   const float lse = work[rows + 8 + row];
   const T* lr = logits + row * V;
   if (vec) {

@@ -2,6 +2,7 @@
 `prepare_batch(batch)` -> (images1, images2, image_masks1, image_masks2, shift_masks1, shift_masks2) on the device.
 Images stay uint8 NHWC (the /255 and the NCHW permute are fused into the HIP front end) unless `float_images=True`;
 masks stay uint8.  Values may be numpy arrays or device tensors (common/dataloader.BatchCreator)."""
+import numpy as np
 import torch
 
 _IMAGE_KEYS = ("images", "images2")
@@ -23,7 +24,13 @@ class BatchOperator:
         return pixels.float().permute(0, 3, 1, 2) / 255.0 if self.float_images else pixels
 
     def _prepare_batch_masks(self, batch, key="image_masks"):
-        return torch.as_tensor(batch[key]).to(self.device, non_blocking=True)
+        value = batch[key]
+        t = torch.as_tensor(value).to(self.device, non_blocking=True)
+        if not (isinstance(value, torch.Tensor) and value.is_cuda):
+            # the losses select rows by these masks: with the host original at hand they build their index lists without a
+            # device sync (losses.host_mask)
+            t._pero_host = value.numpy() if isinstance(value, torch.Tensor) else np.asarray(value)
+        return t
 
     @staticmethod
     def batch_size(batch):

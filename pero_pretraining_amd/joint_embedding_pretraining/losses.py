@@ -1,6 +1,7 @@
 """VICRegLoss and NTXentLoss with the interface of the reference's joint_embedding_pretraining/losses.py,
 computed by HIP kernels: boolean-mask row selections become index gathers, the covariance (a D x D SYRK)
 and the per-line similarity matrices run on pero_gemm, the statistics are f32 reductions."""
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -16,19 +17,36 @@ def _rows(t, dtype):
     return t2
 
 
-def _nz(mask, value=1):
-    # index list of the selected positions (host-visible sizes: one sync per mask, like the reference's
-    # boolean indexing)
-    return torch.nonzero(mask.reshape(-1) == value, as_tuple=False).reshape(-1).contiguous()
+def host_mask(m):
+    """The mask's values on the HOST when they are known there without a device sync: numpy arrays, CPU tensors, and device
+    tensors that the batch operator / collator uploaded from host arrays (they carry the original as `_pero_host`)."""
+    if isinstance(m, np.ndarray):
+        return m
+    if isinstance(m, torch.Tensor):
+        if not m.is_cuda:
+            return m.numpy()
+        return getattr(m, "_pero_host", None)
+    return np.asarray(m)
+
+
+def _nz(mask, device, value=1):
+    """Index list (int64, on `device`) of the positions with mask == value.  With a host copy of the mask the list is built on the
+    host and uploaded asynchronously - no device sync; a mask that exists on the device only costs one torch.nonzero sync, like
+    the reference's boolean indexing (joint_embedding_pretraining/losses.py:14-22)."""
+    h = host_mask(mask)
+    if h is not None:
+        idx = np.flatnonzero(np.asarray(h).reshape(-1) == value).astype(np.int64)
+        return torch.from_numpy(idx).to(device, non_blocking=True)
+    return torch.nonzero(torch.as_tensor(mask).to(device).reshape(-1) == value, as_tuple=False).reshape(-1).contiguous()
 
 
 class _VICRegFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, y, im1, im2, sm1, sm2, wv, wi, wc, thr, eps, dtype, group=None):
+    def forward(ctx, x, y, ix, iy, jx, jy, wv, wi, wc, thr, eps, dtype, group=None):
+        # ix, iy, jx, jy: index lists of the invariance rows (shift masks == 1) and of the statistics rows (image masks == 1)
         # group: a torch.distributed process group -> statistics over the lines of ALL its ranks (see VICRegLoss)
         D = x.shape[-1]
         x2, y2 = _rows(x, dtype), _rows(y, dtype)
-        ix, iy, jx, jy = _nz(sm1), _nz(sm2), _nz(im1), _nz(im2)
         if ix.numel() != iy.numel():
             raise RuntimeError(f"The size of tensor a ({ix.numel()}) must match the size of tensor b ({iy.numel()}) "
                                "at non-singleton dimension 0")  # what mse_loss reports in the reference
@@ -114,8 +132,8 @@ class VICRegLoss(torch.nn.Module):
         if not x.is_cuda:
             raise RuntimeError("pero_pretraining_amd losses run on the GPU only (HIP kernels, no CPU fallback)")
         dev = x.device
-        masks = [torch.as_tensor(m).to(dev) for m in (image_masks1, image_masks2, shift_masks1, shift_masks2)]
-        loss, var, inv, cov = _VICRegFn.apply(x, y, *masks, float(self.variance_weight), float(self.invariance_weight),
+        sel = [_nz(m, dev) for m in (shift_masks1, shift_masks2, image_masks1, image_masks2)]
+        loss, var, inv, cov = _VICRegFn.apply(x, y, *sel, float(self.variance_weight), float(self.invariance_weight),
                                               float(self.covariance_weight), float(self.variance_threshold), self.eps,
                                               compute_dtype(), self._group())
         return {"loss": loss, "loss.variance": var, "loss.invariance": inv, "loss.covariance": cov}
@@ -173,8 +191,8 @@ class NTXentLoss(torch.nn.Module):
         if not x.is_cuda:
             raise RuntimeError("pero_pretraining_amd losses run on the GPU only (HIP kernels, no CPU fallback)")
         for m in (shift_masks1, shift_masks2, image_masks1, image_masks2):
-            mt = torch.as_tensor(m)
-            if bool((mt != 1).any()):
+            h = host_mask(m)   # (checked on the host copy when there is one: no device sync)
+            if bool((np.asarray(h) != 1).any()) if h is not None else bool((torch.as_tensor(m) != 1).any()):
                 raise IndexError("The shape of the mask at index 0 does not match the shape of the indexed tensor "
                                  "(NT-Xent of the reference is only defined for all-ones masks)")
         return {"loss": _NTXentFn.apply(x, y, float(self.temperature), compute_dtype())}

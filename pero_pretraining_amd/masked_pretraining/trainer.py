@@ -36,6 +36,15 @@ class _StepGraph:
 class Trainer:
     def __init__(self, batch_operator, model, dataloader, optimizer, scheduler, bfloat16=False, data_parallel=None,
                  hip_graph=False):
+        if hip_graph:
+            # the captured step replays fixed launches: the bf16 weight refresh must be inside the graph (FusedAdam's own
+            # kernel; torch optimizers would leave the forward on the weights of capture time) and nothing may read the
+            # mask on the host during capture (head_rows == "masked" lists the rows with torch.nonzero)
+            from ..optim import FusedAdam
+            if not isinstance(optimizer, FusedAdam):
+                raise ValueError("Trainer(hip_graph=True) needs optim.FusedAdam")
+            if getattr(model, "head_rows", "all") != "all":
+                raise ValueError("Trainer(hip_graph=True) needs model.head_rows == 'all'")
         self.hip_graph = hip_graph
         self._graphs = {}
         self.batch_operator = batch_operator

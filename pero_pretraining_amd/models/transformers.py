@@ -64,6 +64,8 @@ class _BackboneFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mod, x, mask, offsets, dtype, *params):
         save = any(ctx.needs_input_grad)
+        if save:
+            mod._grad_forwards = getattr(mod, "_grad_forwards", 0) + 1  # parallel.DataParallel overlaps only single-pass steps
         tokens, saved = F.backbone_fwd(mod, x, mask, offsets, dtype, save)
         ctx.mod, ctx.saved, ctx.dtype = mod, saved, dtype
         return tokens
@@ -140,7 +142,15 @@ class TransformerEncoder(ABC, torch.nn.Module):
         if not x.is_cuda:
             raise RuntimeError("pero_pretraining_amd backbones run on the GPU only (HIP kernels, no CPU fallback)")
         if x.dtype != torch.uint8 and mask is not None:
-            self.mask(x, mask)  # reference semantic: the caller's tensor is overwritten in place
+            # reference semantic: the caller's tensor is overwritten in place.  The reference BatchOperator's
+            # `.float().permute(0, 3, 1, 2) / 255` keeps NHWC strides: mask a contiguous copy, write it back, go on with the copy
+            if x.dtype == torch.float32 and not x.is_contiguous():
+                xc = x.contiguous()
+                self.mask(xc, mask)
+                x.copy_(xc)
+                x = xc
+            else:
+                self.mask(x, mask)
             mask = None
         w = x.shape[2] if x.dtype == torch.uint8 else x.shape[3]
         offsets = self.position_model.draw_offsets(x.shape[0], w // self.patch_size[1], x.device)

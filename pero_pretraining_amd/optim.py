@@ -76,7 +76,8 @@ class FusedAdam(torch.optim.Optimizer):
 
     # flat views for data-parallel gradient reduction
     def flat_grads(self):
-        return [f["g"] for f in self._flat if f is not None]
+        """{parameter-group index: flat f32 gradient buffer} (groups without parameters have none)"""
+        return {gi: f["g"] for gi, f in enumerate(self._flat) if f is not None}
 
     def param_offsets(self):
         """{id(param): (group index, start, numel)} inside the flat buffers."""
@@ -152,6 +153,12 @@ class FusedAdam(torch.optim.Optimizer):
         for group, f in zip(self.param_groups, self._flat):
             if f is None:
                 continue
+            # a gradient that no longer aliases the flat buffer (model.zero_grad(set_to_none=True) or `p.grad = ...` made the
+            # backward write a fresh tensor) is copied in and relinked: stepping on the stale flat slice would be silent
+            for p, o in zip(f["params"], f["offsets"]):
+                if p.grad is not None and p.grad.data_ptr() != f["g"].data_ptr() + 4 * o:
+                    f["g"][o:o + p.numel()].copy_(p.grad.reshape(-1))
+                    p.grad = f["g"][o:o + p.numel()].view(p.shape)
             f["step"] += 1
             b1, b2 = group["betas"]
             ops.adam_step(f["p"], f["g"], f["m"], f["v"], f["lp"], group["lr"], b1, b2, group["eps"], f["step"],

@@ -106,7 +106,7 @@ class DataParallel:
         """Called by the backbone's backward when layer `stage` (or -1: the front end) has enqueued its last
         gradient kernel.  Layers are reduced in groups of `layers_per_bucket` (fewer, larger collectives: xGMI ring
         collectives are per-link bound and every launch costs a few microseconds of CU time)."""
-        if not self.active:
+        if not self.active or getattr(self, "_defer", False):
             return
         self._reduce("head")   # complete before the backbone's backward began
         if stage == -1:
@@ -127,7 +127,16 @@ class DataParallel:
         return local_count.detach().to(torch.float32) * float(self.world_size) / total
 
     def begin_backward(self):
+        """Call after the forward pass(es), before loss.backward().  The bucket hooks assume ONE backbone backward per step: a
+        step that ran the backbone forward more than once (the joint model's non-batched fallback) would fire every stage in
+        the first of its backward passes and add the second one's gradients to buckets already reduced - such a step defers
+        all reduction to finish_backward()."""
         self._pending, self._done = [], set()
+        backbone = getattr(self.model, "backbone", None)
+        passes = getattr(backbone, "_grad_forwards", 1) if backbone is not None else 1
+        if backbone is not None:
+            backbone._grad_forwards = 0
+        self._defer = passes > 1
 
     def finish_backward(self):
         """Reduce whatever has not been launched yet and make the compute stream wait for all of it."""

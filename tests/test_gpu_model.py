@@ -31,20 +31,27 @@ def test_state_dict_keys_match_reference(golden):
     assert list(model.state_dict().keys()) == list(sd_from(g).keys())
 
 
-@pytest.mark.parametrize("input_kind", ["u8_nhwc", "f32_nchw"])
+@pytest.mark.parametrize("input_kind", ["u8_nhwc", "f32_nchw", "batch_operator_float_images"])
 def test_masked_tiny_eval_forward_backward(golden, input_kind):
     g = golden("g4_masked_tiny.npz")
     model = build_tiny(sd_from(g)).eval()
     labels = torch.from_numpy(g["labels"]).cuda()
     if input_kind == "u8_nhwc":
         x = torch.from_numpy(g["images"]).cuda()
+    elif input_kind == "batch_operator_float_images":
+        # BatchOperator(float_images=True) hands over the reference's `.float().permute(0, 3, 1, 2) / 255` tensor: NCHW shape,
+        # NHWC strides (not contiguous) - INTEGRATION.md documents this path
+        from pero_pretraining_amd.masked_pretraining.batch_operator import BatchOperator
+        bop = BatchOperator(torch.device("cuda", 0), 0.15, float_images=True)
+        x, lab2, _ = bop.prepare_batch({"images": g["images"], "labels": g["labels"]})
+        assert x.dtype == torch.float32 and x.shape[1] == 3 and not x.is_contiguous() and torch.equal(lab2, labels)
     else:
         x = O.prepare_images(torch.from_numpy(g["images"])).contiguous().cuda()
     res = model(x, labels, g["mask"].copy())
     assert res["output"].shape == g["eval_output"].shape
     assert np.abs(res["output"].detach().float().cpu().numpy() - g["eval_output"]).max() < 1e-4
     assert abs(float(res["loss"]) - float(g["eval_loss"])) < 1e-4 * abs(float(g["eval_loss"]))
-    if input_kind == "f32_nchw":  # reference semantic: backbone.mask overwrites the caller's tensor
+    if input_kind != "u8_nhwc":  # reference semantic: backbone.mask overwrites the caller's tensor
         assert np.array_equal(x[:, :, :, :64].cpu().numpy(), g["masked_images_sample"])
     model.zero_grad()
     res["loss"].backward()

@@ -329,6 +329,24 @@ def test_masked_ce_empty_mask_is_nan(ops):
     assert math.isnan(float(loss))  # reference: cross_entropy over an empty selection is NaN
 
 
+def test_masked_ce_label_outside_the_head_is_nan_not_a_fault(ops):
+    """8192-code labels against a 4096-way head (or a negative label under a set mask bit): F.cross_entropy raises in the
+    reference (masked_pretraining/model.py:82); here the loss and the row's gradient are NaN - no out-of-bounds read."""
+    g = torch.Generator().manual_seed(9)
+    logits = torch.randn(12, 4096, generator=g).bfloat16().cuda()
+    labels = torch.randint(0, 4096, (12,), generator=g).cuda()
+    mask = torch.ones(12, dtype=torch.long).cuda()
+    ok, work = ops.masked_ce_fwd(logits, labels, mask)
+    assert math.isfinite(float(ok))
+    for bad in (5000, -1):
+        lab = labels.clone()
+        lab[3] = bad
+        loss, work = ops.masked_ce_fwd(logits, lab, mask)
+        assert math.isnan(float(loss))
+        dl = ops.masked_ce_bwd(logits, lab, mask, work)
+        assert torch.isnan(dl[3].float()).all() and torch.isfinite(dl[2].float()).all()
+
+
 def test_colsum_cast_scale(ops):
     g = torch.Generator().manual_seed(4)
     x = torch.randn(300, 1000, generator=g)

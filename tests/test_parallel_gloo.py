@@ -56,14 +56,14 @@ class _FlatOpt:
             self.p[o:o + p.numel()].copy_(p.detach().reshape(-1))
             p.data = self.p[o:o + p.numel()].view(p.shape)
             p.grad = self.g[o:o + p.numel()].view(p.shape)
-        self._flat = [dict(p=self.p, g=self.g)]
+        self._flat = [None, dict(p=self.p, g=self.g)]   # group 0 holds no parameters (a frozen / empty group): indices must not shift
         self.ps, self.offs, self.grad_scale, self.refreshed = ps, offs, 1.0, 0
 
     def flat_grads(self):
-        return [self.g]
+        return {1: self.g}
 
     def param_offsets(self):
-        return {id(p): (0, o, p.numel()) for p, o in zip(self.ps, self.offs)}
+        return {id(p): (1, o, p.numel()) for p, o in zip(self.ps, self.offs)}
 
     def refresh_lowp(self):
         self.refreshed += 1
@@ -107,6 +107,24 @@ def _worker(rank, world, port, overlap):
         expect = sum(float(r + 1) * (i + 1) for r in range(world))
         assert torch.all(p.grad == expect), (i, p.grad, expect)
         assert torch.all(p.grad * opt.grad_scale == expect / world)
+    # a step with TWO backbone backward passes (the joint model's non-batched fallback): the hooks of the first pass must
+    # not reduce anything - every gradient is complete only after the second - and finish_backward reduces all of it once
+    if overlap:
+        model.backbone._grad_forwards = 2
+        dp.begin_backward()
+        assert model.backbone._grad_forwards == 0
+        for i, p in enumerate(model.parameters()):
+            p.grad.fill_(float(rank + 1))
+        for stage in (2, 1, 0, -1):
+            model.backbone._on_layer_grads_ready(stage)          # first pass
+        assert not dp._pending and not dp._done
+        for i, p in enumerate(model.parameters()):
+            p.grad.add_(float(rank + 1) * i)                      # second pass accumulates
+        for stage in (2, 1, 0, -1):
+            model.backbone._on_layer_grads_ready(stage)
+        dp.finish_backward()
+        for i, p in enumerate(model.parameters()):
+            assert torch.all(p.grad == sum(float(r + 1) * (1 + i) for r in range(world))), i
     dist.destroy_process_group()
 
 
