@@ -321,6 +321,27 @@ def ntxent_loss(x, y, image_masks1, image_masks2, shift_masks1, shift_masks2, te
     return {"loss": torch.stack(losses).mean()}
 
 
+def ntxent_cross_loss(x, y, lines_per_rank, temperature=0.1):
+    """The cross-rank-negatives EXTENSION of NT-Xent (no reference counterpart; pero_pretraining_amd NTXentLoss(cross_rank_negatives=
+    True)) restated on the CONCATENATED batch x, y (L, S, D) of all ranks: per line the reference's column-normalised softmax
+    (joint_embedding_pretraining/losses.py:73-83) whose normaliser additionally holds one pooled view-1 embedding of every OTHER
+    line, p_l = normalize(mean_i normalize(x_l,i)).  Returns (mean loss over all lines, per-rank mean losses)."""
+    xn = x / torch.sqrt((x * x).sum(dim=-1, keepdim=True)).clamp_min(1e-12)
+    yn = y / torch.sqrt((y * y).sum(dim=-1, keepdim=True)).clamp_min(1e-12)
+    pm = xn.mean(dim=1)
+    p = pm / torch.sqrt((pm * pm).sum(dim=-1, keepdim=True)).clamp_min(1e-12)
+    losses = []
+    for l in range(x.shape[0]):
+        sim = (xn[l] @ yn[l].t()) / temperature                      # [i, j]
+        neg = (p @ yn[l].t()) / temperature                          # [l', j]
+        keep = torch.ones(x.shape[0], dtype=torch.bool)
+        keep[l] = False
+        denom = torch.exp(sim).sum(dim=0) + torch.exp(neg[keep]).sum(dim=0)
+        losses.append((torch.log(denom) - torch.diag(sim)).mean())
+    losses = torch.stack(losses)
+    return losses.mean(), losses.view(-1, lines_per_rank).mean(dim=1)
+
+
 def joint_model_forward(sd, images1_nchw, images2_nchw, masks, num_heads, loss="vicreg",
                         offsets1=None, offsets2=None, max_len=4096):
     """JointEmbeddingTransformerEncoder.forward with a LinearHead.

@@ -178,14 +178,90 @@ class _NTXentFn(torch.autograd.Function):
         return dx.view(n, s, D), dy.view(n, s, D), None, None
 
 
+class _BmmNT(torch.autograd.Function):
+    """per line: out[l] = a[l] @ b[l]^T * alpha   (N, S, D) x (N, T, D) -> (N, S, T) f32, on batched pero_gemm"""
+
+    @staticmethod
+    def forward(ctx, a, b, alpha):
+        n, s, D = a.shape
+        t = b.shape[1]
+        out = torch.empty((n, s, t), device=a.device, dtype=torch.float32)
+        ops.gemm_raw(a, b, out, s, t, D, D, D, t, batch=n, sA=(s * D, 0), sB=(t * D, 0), sC=(s * t, 0), alpha=alpha)
+        ctx.save_for_backward(a, b)
+        ctx.alpha = alpha
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        n, s, D = a.shape
+        t = b.shape[1]
+        gd = g.contiguous().to(a.dtype)
+        da, db = torch.empty_like(a), torch.empty_like(b)
+        ops.gemm_raw(gd, b, da, s, D, t, t, D, D, batch=n, sA=(s * t, 0), sB=(t * D, 0), sC=(s * D, 0), alpha=ctx.alpha, flags=GEMM_TRANS_B)
+        ops.gemm_raw(gd, a, db, t, D, s, t, D, D, batch=n, sA=(s * t, 0), sB=(s * D, 0), sC=(t * D, 0), alpha=ctx.alpha,
+                     flags=GEMM_TRANS_A | GEMM_TRANS_B)
+        return da, db, None
+
+
+class _MmNT(torch.autograd.Function):
+    """out = a @ b^T * alpha   (M, D) x (L, D) -> (M, L) f32, on pero_gemm"""
+
+    @staticmethod
+    def forward(ctx, a, b, alpha):
+        out = ops.gemm(a, b, alpha=alpha, out_dtype=torch.float32)
+        ctx.save_for_backward(a, b)
+        ctx.alpha = alpha
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        gd = g.contiguous().to(a.dtype)
+        da = ops.gemm(gd, b, trans_b=True, alpha=ctx.alpha)                  # (M, L) x (L, D)
+        db = ops.gemm(gd, a, trans_a=True, trans_b=True, alpha=ctx.alpha)    # (L, M) x (M, D)
+        return da, db, None
+
+
+class _AllGatherRows(torch.autograd.Function):
+    """all-gather of equally shaped row blocks over the ranks; backward: every rank's gradient block summed back to its owner"""
+
+    @staticmethod
+    def forward(ctx, t, group):
+        ctx.group, ctx.world, ctx.rank = group, dist.get_world_size(group), dist.get_rank(group)
+        parts = [torch.empty_like(t) for _ in range(ctx.world)]
+        dist.all_gather(parts, t.contiguous(), group=group)
+        return torch.cat(parts, dim=0)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=ctx.group)   # (reduce-scatter semantics; all-reduce keeps gloo and RCCL on one path)
+        n = g.shape[0] // ctx.world
+        return g[ctx.rank * n:(ctx.rank + 1) * n].clone(), None
+
+
 class NTXentLoss(torch.nn.Module):
     """joint_embedding_pretraining/losses.py:51-83.  Like the reference, only all-ones masks are valid: the
     reference indexes the shift-reduced similarity matrix with the full-length image masks (losses.py:78) and
-    raises IndexError for every other input; the same exception is raised here."""
+    raises IndexError for every other input; the same exception is raised here.
 
-    def __init__(self, temperature=0.1):
+    cross_rank_negatives=True (BASELINE.json configs[4] / north_star; NO reference counterpart - the reference's loss is per line,
+    SURVEY.md section 8e): every line additionally contributes ONE pooled embedding p = normalize(mean over its positions of the
+    normalised view-1 rows); the pooled embeddings of all ranks are all-gathered (a bounded exchange: world x N x D values per
+    step - 33.5 MB in bf16 for 8 ranks x 512 lines x 4096, not the 1 GB per rank of the full embeddings) and enter every column's
+    normaliser as negatives, the line's own pooled embedding excepted:
+        loss_line = mean_j [ log( sum_i exp(x_i . y_j / T) + sum_{lines l' != line, all ranks} exp(p_l' . y_j / T) ) - x_j . y_j / T ].
+    Gradients flow back through the gathered rows to the rank that owns them (sum over ranks), so the data-parallel average of
+    the parameter gradients is the gradient of the mean loss over the global batch.  The restatement on the concatenated batch is
+    oracle/pero_oracle.py::ntxent_cross_loss; the heavy products run on pero_gemm, the exponentials on torch elementwise kernels
+    (an extension outside the reference-parity path)."""
+
+    def __init__(self, temperature=0.1, cross_rank_negatives=False, process_group=None):
         super().__init__()
         self.temperature = temperature
+        self.cross_rank_negatives = cross_rank_negatives
+        self.process_group = process_group
 
     def forward(self, x, y, image_masks1, image_masks2, shift_masks1, shift_masks2):
         if not x.is_cuda:
@@ -195,4 +271,27 @@ class NTXentLoss(torch.nn.Module):
             if bool((np.asarray(h) != 1).any()) if h is not None else bool((torch.as_tensor(m) != 1).any()):
                 raise IndexError("The shape of the mask at index 0 does not match the shape of the indexed tensor "
                                  "(NT-Xent of the reference is only defined for all-ones masks)")
-        return {"loss": _NTXentFn.apply(x, y, float(self.temperature), compute_dtype())}
+        if not self.cross_rank_negatives:
+            return {"loss": _NTXentFn.apply(x, y, float(self.temperature), compute_dtype())}
+        return {"loss": self._cross(x, y)}
+
+    def _cross(self, x, y):
+        dtype, T = compute_dtype(), float(self.temperature)
+        n, s, D = x.shape
+        group = None
+        if dist.is_available() and dist.is_initialized():
+            group = self.process_group if self.process_group is not None else dist.group.WORLD
+        xn = torch.nn.functional.normalize(x.float(), dim=-1, eps=1e-12)
+        yn = torch.nn.functional.normalize(y.float(), dim=-1, eps=1e-12)
+        pooled = torch.nn.functional.normalize(xn.mean(dim=1), dim=-1, eps=1e-12)          # (N, D): one bounded negative per line
+        gathered = _AllGatherRows.apply(pooled, group) if group is not None else pooled        # (L, D), L = world * N
+        rank = dist.get_rank(group) if group is not None else 0
+        xl, yl = xn.to(dtype).contiguous(), yn.to(dtype).contiguous()
+        sim = _BmmNT.apply(xl, yl, 1.0 / T)                                                    # (N, S, S): sim[l, i, j] = x_i . y_j / T
+        cross = _MmNT.apply(yl.view(n * s, D), gathered.to(dtype).contiguous(), 1.0 / T)       # (N*S, L): y_j . p_l' / T
+        cross = cross.view(n, s, -1)
+        own = torch.arange(n, device=x.device) + rank * n
+        cross = cross.masked_fill(torch.nn.functional.one_hot(own, cross.shape[-1]).bool()[:, None, :], float("-inf"))
+        lse = torch.logsumexp(torch.cat([sim.transpose(1, 2), cross], dim=-1), dim=-1)         # per (line, column j): over i and l'
+        diag = torch.diagonal(sim, dim1=1, dim2=2)
+        return (lse - diag).mean(dim=1).mean()

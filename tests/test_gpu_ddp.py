@@ -193,3 +193,108 @@ def test_two_rank_global_vicreg_statistics_equal_the_loss_on_the_concatenated_ba
         for have, want in ((dx, xo.grad[rows].numpy()), (dy, yo.grad[rows].numpy())):
             # seeded with world_size: the data-parallel average (divide by 2) gives the single-process gradient
             assert np.abs(have / 2 - want).max() <= 1e-4 * np.abs(want).max()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# NT-Xent with cross-rank negatives (extension; BASELINE.json configs[4]): two ranks == the oracle on the concatenated batch
+def _ntxent_cross_worker(rank, world, port, out_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pero_pretraining_amd.joint_embedding_pretraining.losses import NTXentLoss
+    rng = np.random.default_rng(7)
+    n, s, D = 3, 16, 64
+    xa = rng.standard_normal((world * n, s, D)).astype(np.float32)
+    ya = (xa + 0.5 * rng.standard_normal((world * n, s, D))).astype(np.float32)
+    x = torch.from_numpy(xa[rank * n:(rank + 1) * n]).cuda().requires_grad_(True)
+    y = torch.from_numpy(ya[rank * n:(rank + 1) * n]).cuda().requires_grad_(True)
+    ones = np.ones((n, s), np.uint8)
+    loss = NTXentLoss(cross_rank_negatives=True)(x, y, ones, ones, ones, ones)["loss"]
+    loss.backward()
+    torch.cuda.synchronize()
+    out_q.put((rank, float(loss), x.grad.cpu().numpy(), y.grad.cpu().numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ntxent_cross_rank_negatives_two_ranks_equal_the_oracle_on_the_concatenated_batch():
+    from oracle import pero_oracle as O
+    world, n, s, D = 2, 3, 16, 64
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ntxent_cross_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    rng = np.random.default_rng(7)
+    xa = rng.standard_normal((world * n, s, D)).astype(np.float32)
+    ya = (xa + 0.5 * rng.standard_normal((world * n, s, D))).astype(np.float32)
+    xo = torch.from_numpy(xa).double().requires_grad_(True)
+    yo = torch.from_numpy(ya).double().requires_grad_(True)
+    mean, per_rank = O.ntxent_cross_loss(xo, yo, n)
+    (per_rank.sum()).backward()        # every rank differentiates ITS loss; gradients through the gathered rows are summed back
+    for r, loss, gx, gy in res:
+        assert abs(loss - float(per_rank[r])) < 1e-4 * abs(float(per_rank[r])), (r, loss, float(per_rank[r]))
+        rx, ry = xo.grad[r * n:(r + 1) * n].numpy(), yo.grad[r * n:(r + 1) * n].numpy()
+        assert np.abs(gx - rx).max() < 1e-4 * np.abs(rx).max() + 1e-8, r
+        assert np.abs(gy - ry).max() < 1e-4 * np.abs(ry).max() + 1e-8, r
+    assert abs(sum(t[1] for t in res) / world - float(mean)) < 1e-4 * float(mean)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the joint-embedding Trainer under data parallelism (two ranks, one device, gloo)
+def _joint_dp_worker(rank, world, port, out_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pero_pretraining_amd.common.lr_scheduler import WarmupSchleduler
+    from pero_pretraining_amd.joint_embedding_pretraining.batch_operator import BatchOperator
+    from pero_pretraining_amd.joint_embedding_pretraining.losses import VICRegLoss
+    from pero_pretraining_amd.joint_embedding_pretraining.model import JointEmbeddingTransformerEncoder, LinearHead
+    from pero_pretraining_amd.joint_embedding_pretraining.trainer import Trainer
+    from pero_pretraining_amd.models.transformers import VisionTransformerEncoder
+    from pero_pretraining_amd.optim import FusedAdam
+    from pero_pretraining_amd.parallel import DataParallel
+    torch.manual_seed(3)
+    bb = VisionTransformerEncoder(num_blocks=2, model_dim=64, num_heads=4, feedforward_dim=128)
+    model = JointEmbeddingTransformerEncoder(bb, LinearHead(in_features=64, out_features=80), VICRegLoss()).cuda().train()
+    opt = FusedAdam(model.parameters(), lr=1e-3)
+    dp = DataParallel(model, opt)
+    trainer = Trainer(BatchOperator(torch.device("cuda", 0)), model, None, opt, WarmupSchleduler(opt, 1e-3, 0, 1), data_parallel=dp)
+    rng = np.random.default_rng(50 + rank)
+    n, S = 3, 24
+    ones = np.ones((n, S), np.uint8)
+    sm = ones.copy()
+    sm[:, :2] = 0
+    batch = {"images": rng.integers(0, 256, (n, 40, S * 8, 3), dtype=np.uint8), "images2": rng.integers(0, 256, (n, 40, S * 8, 3), dtype=np.uint8),
+             "image_masks": ones, "image_masks2": ones, "shift_masks": sm, "shift_masks2": sm[:, ::-1].copy()}
+    model.backbone.set_offsets(np.arange(n) + 7 * rank, np.arange(n) + 100 + rank)
+    loss = trainer.train_step(batch)
+    torch.cuda.synchronize()
+    params = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu()
+    gathered = [torch.empty_like(params) for _ in range(world)]
+    dist.all_gather(gathered, params)
+    out_q.put((rank, float(loss), all(torch.equal(gathered[0], g) for g in gathered), bool(torch.isfinite(params).all())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_joint_trainer_two_rank_data_parallel_step_keeps_the_ranks_identical():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_joint_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert all(same and finite and np.isfinite(loss) for _, loss, same, finite in res)
+    assert abs(res[0][1] - res[1][1]) > 0     # different shards, different losses

@@ -173,3 +173,29 @@ def test_vector_quantizer_module_matches_reference_golden(golden):
     km = kmeans_labels(cu(g["small.features"][:, :, 0, :]), cu(g["small.codebook"]))
     assert np.array_equal(km.cpu().numpy().reshape(-1), g["small.kmeans_indices"])
     # training mode (EMA codebook update) is covered by tests/test_gpu_next_rows.py::test_vq_training_mode_matches_reference
+
+
+def test_ntxent_cross_rank_negatives_single_process_matches_the_oracle():
+    """world of one: the pooled embeddings of the OTHER lines of the same batch are the negatives (f32 parity mode and bf16)."""
+    import pero_pretraining_amd as P
+    from pero_pretraining_amd.joint_embedding_pretraining.losses import NTXentLoss
+    rng = np.random.default_rng(3)
+    n, s, D = 5, 32, 128
+    x = rng.standard_normal((n, s, D)).astype(np.float32)
+    y = (x + 0.4 * rng.standard_normal((n, s, D))).astype(np.float32)
+    xo, yo = torch.from_numpy(x).double().requires_grad_(True), torch.from_numpy(y).double().requires_grad_(True)
+    ref, _ = O.ntxent_cross_loss(xo, yo, n)
+    ref.backward()
+    ones = torch.ones((n, s), dtype=torch.uint8)
+    xg, yg = cu(x).requires_grad_(True), cu(y).requires_grad_(True)
+    res = NTXentLoss(cross_rank_negatives=True)(xg, yg, ones, ones, ones, ones)
+    assert abs(float(res["loss"]) - float(ref)) < 1e-4 * float(ref)
+    res["loss"].backward()
+    assert np.abs(xg.grad.cpu().numpy() - xo.grad.numpy()).max() < 1e-4 * np.abs(xo.grad.numpy()).max() + 1e-8
+    assert np.abs(yg.grad.cpu().numpy() - yo.grad.numpy()).max() < 1e-4 * np.abs(yo.grad.numpy()).max() + 1e-8
+    plain = NTXentLoss()(cu(x), cu(y), ones, ones, ones, ones)["loss"]
+    assert float(res["loss"]) > float(plain)        # more negatives in every normaliser
+    xb, yb = cu(x).bfloat16().requires_grad_(True), cu(y).bfloat16().requires_grad_(True)
+    with P.autocast(True):
+        rb = NTXentLoss(cross_rank_negatives=True)(xb, yb, ones, ones, ones, ones)
+    assert abs(float(rb["loss"]) - float(ref)) < 3e-2 * float(ref)

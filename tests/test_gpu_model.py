@@ -51,8 +51,16 @@ def test_masked_tiny_eval_forward_backward(golden, input_kind):
     assert res["output"].shape == g["eval_output"].shape
     assert np.abs(res["output"].detach().float().cpu().numpy() - g["eval_output"]).max() < 1e-4
     assert abs(float(res["loss"]) - float(g["eval_loss"])) < 1e-4 * abs(float(g["eval_loss"]))
-    if input_kind != "u8_nhwc":  # reference semantic: backbone.mask overwrites the caller's tensor
+    if input_kind == "f32_nchw":  # reference semantic: backbone.mask overwrites the caller's tensor
         assert np.array_equal(x[:, :, :, :64].cpu().numpy(), g["masked_images_sample"])
+    elif input_kind == "batch_operator_float_images":
+        # same, through the non-contiguous tensor; its x / 255 ran on the GPU (torch's device division is within 1 ulp of the
+        # CPU's, not bit-equal), the overwritten noise-tile columns are exact copies
+        got = x[:, :, :, :64].cpu().numpy()
+        assert np.abs(got - g["masked_images_sample"]).max() < 1e-7
+        cols = np.repeat(g["mask"][:, :8].astype(bool), 8, axis=1)
+        sel = np.broadcast_to(cols[:, None, None, :], got.shape)
+        assert sel.any() and np.array_equal(got[sel], g["masked_images_sample"][sel])
     model.zero_grad()
     res["loss"].backward()
     for k, p in model.named_parameters():

@@ -126,8 +126,8 @@ def test_mlp_head_matches_reference_golden(golden):
 def test_joint_trainer_three_steps_match_the_reference_trainer(golden):
     """joint_embedding_pretraining/trainer.py:46-61 through OUR Trainer.train_step + BatchOperator + FusedAdam (f32 parity mode):
     per-step loss and loss parts within 1e-4; final weights within one learning-rate step (1e-3 of the 3e-3 a parameter can move
-    in three Adam steps) everywhere and within 1e-4 on average - Adam's g / sqrt(v) turns the rounding noise of the near-zero
-    VICReg gradients (LayerNorm biases of the last layer) into updates of either sign, element by element."""
+    in three Adam steps) everywhere and within 1e-4 on average; parameters whose VICReg gradient is mathematically zero are only
+    bounded by the three steps they can take."""
     from pero_pretraining_amd.common.lr_scheduler import WarmupSchleduler
     from pero_pretraining_amd.joint_embedding_pretraining.batch_operator import BatchOperator
     from pero_pretraining_amd.joint_embedding_pretraining.losses import VICRegLoss
@@ -162,4 +162,10 @@ def test_joint_trainer_three_steps_match_the_reference_trainer(golden):
             if k.endswith("in_proj_bias"):  # key-bias slice: mathematically zero gradient, Adam amplifies rounding noise
                 d = got.shape[0] // 3
                 got, ref = np.delete(got, np.s_[d:2 * d]), np.delete(ref, np.s_[d:2 * d])
+            if k in ("head.linear.bias", "backbone.encoder_layers.layers.1.norm2.bias"):
+                # a constant added to every token (the last LayerNorm's bias, the head's bias) shifts every output row alike:
+                # VICReg's invariance (a difference), variance and covariance (centred) do not see it - the gradient is
+                # mathematically zero and Adam's g / sqrt(v) turns its rounding noise into +-lr steps in both runs
+                assert np.abs(got - ref).max() <= 3 * 1e-3 + 1e-6, k
+                continue
             assert np.abs(got - ref).max() < 1e-3 and np.abs(got - ref).mean() < 1e-4, (k, float_images, np.abs(got - ref).max())
