@@ -30,7 +30,14 @@ __device__ __forceinline__ bf16raw f2bf(float f) {  // round-to-nearest-even, Na
   __bf16 h = (__bf16)f;
   return __builtin_bit_cast(bf16raw, h);
 }
-__device__ __forceinline__ unsigned pack2bf(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
+// two floats -> one dword of two bf16 (lo in bits 0-15): ONE v_cvt_pk_bf16_f32.  (Two scalar casts joined by shift / or compile to
+// two conversions + a shift + an SDWA or: 4 instructions per dword in every epilogue.)
+__device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
+  typedef float pk_f2 __attribute__((ext_vector_type(2)));
+  typedef __bf16 pk_b2 __attribute__((ext_vector_type(2)));
+  const pk_f2 v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, pk_b2));
+}
 
 template <typename T> struct Elem;
 template <> struct Elem<float> {

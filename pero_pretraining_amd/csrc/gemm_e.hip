@@ -439,7 +439,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p, int ks) {
           E_WAIT8(2 + 2 + CN::L1, side0);
         }
         if (CN::L1 && ha == 1) E_WAIT8(CN::S_HALF, side1);
-        if (EPI == EP_GATE_BITS && ha == 0) {  // landed long ago (retired by phase 4's wait); the statement ties the registers to it
+        if (EPI == EP_GATE_BITS && ha == 0) {
+          // retired by phase 4's wait of the last K-tile long ago (the statements tie the registers to a wait)
           E_WAIT4(63, sm0);
           E_WAIT4(63, sm1);
         }
