@@ -37,7 +37,8 @@
 #define E_KTILE (4 * E_HALF)       // A0 A1 B0 B1
 #define E_RING (2 * E_KTILE)       // 128 KiB: two K-tiles
 #define E_BIAS E_RING              // 8 x 1 KiB: each wave's copy of the tile's 256 bias floats
-#define E_LDS_BYTES (E_RING + 8192 + 512)   // + 512 B of phase stamps (diagnostic build VAR 64)
+#define E_LUT (E_RING + 8192 + 512)           // EP_GATE_BITS: 256 x 16 B, mask byte -> the four AND masks of its 8 bf16 columns
+#define E_LDS_BYTES (E_RING + 8192 + 512 + 4096)   // + 512 B of phase stamps (diagnostic build VAR 64) + the LUT
 
 // epilogue modes
 #define EP_PLAIN 0       // bias
@@ -240,6 +241,16 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p, int ks) {
     const int delay = (int)((long long)period * (gr * 8 + xcd) / (ngr * 8));
     for (int i = 0; i < delay; i += 1024) __builtin_amdgcn_s_sleep(16);
   }
+  if (EPI == EP_GATE_BITS) {
+    // bit e of a mask byte keeps column e of the lane's 8: dword k holds columns 2k (low half) and 2k + 1
+    if (tid < 256) {
+      eu4v m;
+#pragma unroll
+      for (int k = 0; k < 4; k++) m[k] = (((tid >> (2 * k)) & 1) ? 0x0000ffffu : 0u) | (((tid >> (2 * k + 1)) & 1) ? 0xffff0000u : 0u);
+      *(eu4v*)(smem + E_LUT + tid * 16) = m;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // visible to every wave behind the prologue's barrier
+  }
   // ---- prologue: K-tile 0 and all of K-tile 1 (a tile's A1(1) is always issued ahead of its first K-tile)
   issue(0, 2, smem); issue(0, 0, smem); issue(0, 3, smem); issue(0, 1, smem);
   issue(1, 2, smem + E_KTILE); issue(1, 0, smem + E_KTILE); issue(1, 3, smem + E_KTILE); issue(1, 1, smem + E_KTILE);
@@ -355,7 +366,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p, int ks) {
       // normally the three half tiles of t+2; in a tile's first K-tile also the previous epilogue (side loads of rows 64-127,
       // stores) and the bias row; in its last K-tile the side loads issued just above.
       if (!last && t == 0 && first) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");  // + the bias row
-      else if (!last && t == 0 && !first && colsum) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(6 + 1 + CN::L1 + 2 * CN::S_HALF + 16) : "memory");  // + the 16 column-sum atomics
+      else if (!last && t == 0 && !first && colsum) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(6 + 1 + CN::L1 + 2 * CN::S_HALF + 1) : "memory");  // + the column-sum atomic
       else if (!last && t == 0 && !first) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(6 + 1 + CN::L1 + 2 * CN::S_HALF) : "memory");
       else if (CN::L0 && last) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(6 + CN::L0) : "memory");
       else if (EPI == EP_SPLITK && t + 2 >= nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stream has ended
@@ -491,10 +502,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p, int ks) {
             if (EPI == EP_GATE_BITS) {
               const eu2v mm = ha ? sm1[i] : sm0[i];
               const unsigned byte = ((hb ? mm[1] : mm[0]) >> (8 * cq)) & 0xffu;
+              const eu4v keep = *(const eu4v*)(smem + E_LUT + byte * 16);
 #pragma unroll
               for (int k = 0; k < 4; k++) {
-                const unsigned keep = (((byte >> (2 * k)) & 1u) ? 0x0000ffffu : 0u) | (((byte >> (2 * k + 1)) & 1u) ? 0xffff0000u : 0u);
-                o[k] &= keep;
+                o[k] &= keep[k];
                 if (colsum) { cs[hb][2 * k] += __uint_as_float(o[k] << 16); cs[hb][2 * k + 1] += __uint_as_float(o[k] & 0xffff0000u); }
               }
             }
@@ -539,21 +550,30 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p, int ks) {
         }
       }
       if (colsum) {
-        // column sums of the tile's 128 rows of this wave: over the 16 rows of a lane group by shuffles, then one atomic per column
+        // column sums of the tile's 128 rows of this wave.  A lane holds 16 partial sums (its 8 columns x 2 B halves) of its
+        // row; a halving butterfly over the 16 rows of the lane group (xor 8, 4, 2, 1: each step a lane keeps half of its
+        // values and adds the partner's copy of them - 15 exchanges instead of 64) leaves the total of value `li` on lane li,
+        // and ONE atomic instruction with all 64 lanes adds the wave's 64 column sums
+        float w8[8], w4[4], w2[2];
 #pragma unroll
-        for (int hb = 0; hb < 2; hb++)
-#pragma unroll
-          for (int e = 0; e < 8; e++) {
-            float s = cs[hb][e];
-            s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
-            cs[hb][e] = s;
-          }
-        if (li == 0) {
-#pragma unroll
-          for (int hb = 0; hb < 2; hb++)
-#pragma unroll
-            for (int e = 0; e < 8; e++) atomicAdd((float*)p.bias + tn0 + 64 * wc + 32 * hb + c8 + e, cs[hb][e]);
+        for (int j = 0; j < 8; j++) {
+          const float a = cs[0][j], b2 = cs[1][j];
+          const float send = (li & 8) ? a : b2, keepv = (li & 8) ? b2 : a;
+          w8[j] = keepv + __shfl_xor(send, 8, 64);
         }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const float send = (li & 4) ? w8[j] : w8[j + 4], keepv = (li & 4) ? w8[j + 4] : w8[j];
+          w4[j] = keepv + __shfl_xor(send, 4, 64);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          const float send = (li & 2) ? w4[j] : w4[j + 2], keepv = (li & 2) ? w4[j + 2] : w4[j];
+          w2[j] = keepv + __shfl_xor(send, 2, 64);
+        }
+        const float send = (li & 1) ? w2[0] : w2[1], keepv = (li & 1) ? w2[1] : w2[0];
+        const float tot = keepv + __shfl_xor(send, 1, 64);     // value index li = 8 * hb + e
+        atomicAdd((float*)p.bias + tn0 + 64 * wc + 32 * (li >> 3) + c8 + (li & 7), tot);
       }
     }
     E_STAMP(2);
