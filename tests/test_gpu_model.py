@@ -223,3 +223,40 @@ def test_head_on_masked_rows_only_gives_the_same_step(golden):
     # nothing masked: the reference's NaN (mean over an empty selection)
     sparse.train()
     assert np.isnan(float(sparse(images, torch.from_numpy(labels).cuda(), np.zeros_like(mask))["loss"]))
+
+
+def test_hip_graph_step_equals_eager_step(golden):
+    """Trainer(hip_graph=True): zero_grad -> forward -> backward replayed from a captured hipGraph gives the losses and
+    the weights of the eager Trainer over three optimizer steps with changing batches (eval mode: no offset draws, so
+    both runs see the same inputs; the kernels and their order are the same, atomics aside)."""
+    import copy
+    from pero_pretraining_amd.common.lr_scheduler import WarmupSchleduler
+    from pero_pretraining_amd.masked_pretraining.trainer import Trainer
+    from pero_pretraining_amd.optim import FusedAdam
+    g = golden("g5_trajectory.npz")
+    eager = build_tiny(sd_from(g, "sd0.")).eval()
+    graph = copy.deepcopy(eager)
+    runs = {}
+    for name, model, flag in (("eager", eager, False), ("graph", graph, True)):
+        opt = FusedAdam(model.parameters(), lr=2e-3)
+        sched = WarmupSchleduler(opt, 2e-3, 2, 1)
+        trainer = Trainer(None, model, None, opt, sched, bfloat16=True, hip_graph=flag)
+        losses = []
+        for i in range(3):
+            sched.update_learning_rate(i + 1)
+            images = torch.from_numpy(g["images"][i]).cuda()
+            labels = torch.from_numpy(g["labels"][i]).cuda()
+            mask = torch.from_numpy(g["mask"][i]).cuda()
+            losses.append(float(trainer.train_step_prepared(images, labels, mask)))
+        torch.cuda.synchronize()
+        runs[name] = (losses, {k: v.detach().float().cpu().numpy() for k, v in model.state_dict().items()})
+        if flag:
+            assert len(trainer._graphs) == 1   # one capture, three replays
+    for a, b in zip(runs["eager"][0], runs["graph"][0]):
+        assert np.isfinite(a) and abs(a - b) <= 1e-5 * abs(a), runs
+    for k, v in runs["eager"][1].items():
+        w = runs["graph"][1][k]
+        if k.endswith("in_proj_bias"):  # key-bias slice: zero gradient up to rounding noise, which Adam turns into +-lr steps
+            d = v.shape[0] // 3
+            v, w = np.delete(v, np.s_[d:2 * d]), np.delete(w, np.s_[d:2 * d])
+        assert np.abs(v - w).max() <= 1e-4, k
