@@ -373,13 +373,11 @@ __global__ __launch_bounds__(128) void attn_bias_reduce_k(const float* partial, 
   if (i0 < i1) atomicAdd(dbias + (long long)which * nh * 128 + head * 128 + c, s0 + s1);
 }
 
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_k(const bf16raw* qkv, const bf16raw* out, const bf16raw* dout, const float* lse2,
-                                                        float* dvec, bf16raw* dqkv, float* dbias, int S, int nh, float c, float scale) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+__device__ __forceinline__ void attn_bwd_dq_body(unsigned char* smem, int lh, int qb, const bf16raw* qkv, const bf16raw* out,
+                                                 const bf16raw* dout, const float* lse2, float* dvec, bf16raw* dqkv, float* dbias, int S,
+                                                 int nh, float c, float scale) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h5 = lane >> 5, r = lane & 31;
   const int nqb = S >> 7;
-  int lh, qb;
-  attn_block_map(blockIdx.x, nqb, gridDim.x / nqb, lh, qb);
   const int line = lh / nh, head = lh % nh;
   const long long d = (long long)nh * 128, ld = 3 * d;
   const bf16raw* base = qkv + (long long)line * S * ld + head * 128;
@@ -464,6 +462,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_k(const bf16raw* qkv, cons
   attn_store_tile(dq, smem, dqkv + ((long long)line * S + qb * 128) * ld + head * 128, ld,
                   dbias ? dbias + ((long long)lh * nqb + qb) * 128 : nullptr, tid, wave, r, h5);
 }
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_k(const bf16raw* qkv, const bf16raw* out, const bf16raw* dout, const float* lse2,
+                                                        float* dvec, bf16raw* dqkv, float* dbias, int S, int nh, float c, float scale) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int nqb = S >> 7;
+  int lh, qb;
+  attn_block_map(blockIdx.x, nqb, gridDim.x / nqb, lh, qb);
+  attn_bwd_dq_body(smem, lh, qb, qkv, out, dout, lse2, dvec, dqkv, dbias, S, nh, c, scale);
+}
 
 // dK and dV in ONE pass (4 products: S, dP, dV^T += dO^T P, dK^T += Q^T dS; key on the lane).  The two-launch form read
 // Q, dO and K twice and computed S twice (605 MB and 5 products per layer at S = 256, d = 512); both launches were HBM-bound
@@ -471,15 +477,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_k(const bf16raw* qkv, cons
 // was register-resident V next to register-resident K and two accumulator sets; here the workgroup's 128 x 128 V tile
 // lives in LDS (read as the B operand of dP) and Q / dO arrive in 32-query stages (8 + 8 KiB, double-buffered), so the
 // footprint stays at 64.5 KiB = two workgroups per CU.
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv2_k(const bf16raw* qkv, const bf16raw* dout, const float* lse2, const float* dvec,
-                                                          bf16raw* dqkv, float* dbias, int S, int nh, float c, float scale) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+__device__ __forceinline__ void attn_bwd_dkv2_body(unsigned char* smem, int lh, int kb, long long nwg, const bf16raw* qkv, const bf16raw* dout,
+                                                   const float* lse2, const float* dvec, bf16raw* dqkv, float* dbias, int S, int nh, float c,
+                                                   float scale) {
   unsigned char* vimg = smem + 4 * AT_SUB_BYTES;
   float* lds_ld = (float*)(smem + 4 * AT_SUB_BYTES + AT_TILE_BYTES);  // [2 buffers][32 lse2 | 32 D]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h5 = lane >> 5, r = lane & 31;
   const int nkb = S >> 7;
-  int lh, kb;
-  attn_block_map(blockIdx.x, nkb, gridDim.x / nkb, lh, kb);
   const int line = lh / nh, head = lh % nh;
   const long long d = (long long)nh * 128, ld = 3 * d;
   const bf16raw* base = qkv + (long long)line * S * ld + head * 128;
@@ -548,11 +552,35 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv2_k(const bf16raw* qkv, co
     if (sq + 1 < nsub && tid < 64) lds_ld[((sq + 1) & 1) * 64 + tid] = nstat;  // visible after the next barrier
   }
   bf16raw* tile_o = dqkv + ((long long)line * S + kb * 128) * ld + d + head * 128;  // dK tile; dV tile = + d columns
-  const long long nwg = gridDim.x;  // planes 1 (dK) and 2 (dV) of the partial-sum workspace
+  // planes 1 (dK) and 2 (dV) of the partial-sum workspace, nwg = (line, head) x key blocks entries each
   attn_store_tile(dk, smem, tile_o, ld, dbias ? dbias + (nwg + (long long)lh * nkb + kb) * 128 : nullptr, tid, wave, r, h5);
   attn_store_tile(dv, smem, tile_o + d, ld, dbias ? dbias + (2 * nwg + (long long)lh * nkb + kb) * 128 : nullptr, tid, wave, r, h5);
 }
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv2_k(const bf16raw* qkv, const bf16raw* dout, const float* lse2, const float* dvec,
+                                                          bf16raw* dqkv, float* dbias, int S, int nh, float c, float scale) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int nkb = S >> 7;
+  int lh, kb;
+  attn_block_map(blockIdx.x, nkb, gridDim.x / nkb, lh, kb);
+  attn_bwd_dkv2_body(smem, lh, kb, gridDim.x, qkv, dout, lse2, dvec, dqkv, dbias, S, nh, c, scale);
+}
+// Both backward kernels as ONE launch (D already computed: `out` is not read, so no workgroup depends on another): the 2 x (S / 128)
+// workgroups of a (line, head) - its dQ blocks and its dK / dV blocks, which all read the same Q, K, V and dO rows - sit next to
+// each other in one XCD's dispatch order, so the rows come from HBM once and the other readers find them in that XCD's L2
+// (FETCH_SIZE of the backward at 256 lines: 534 MB as two launches, 308 MB paired, 267 MB = each row once; 789 -> 740 us at 1024 lines).
+__global__ __launch_bounds__(256, 2) void attn_bwd_pair_k(const bf16raw* qkv, const bf16raw* dout, const float* lse2, float* dvec,
+                                                          bf16raw* dqkv, float* dbias, int S, int nh, float c, float scale) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int nb = S >> 7;
+  int lh, blk;
+  attn_block_map(blockIdx.x, 2 * nb, gridDim.x / (2 * nb), lh, blk);
+  if (blk < nb)
+    attn_bwd_dq_body(smem, lh, blk, qkv, nullptr, dout, lse2, dvec, dqkv, dbias, S, nh, c, scale);
+  else
+    attn_bwd_dkv2_body(smem, lh, blk - nb, (long long)(gridDim.x >> 1), qkv, dout, lse2, dvec, dqkv, dbias, S, nh, c, scale);
+}
 
+int g_attn_bwd_pair = 1;  // pero_set_option("attn_bwd_pair", 0 / 1)
 extern "C" int pero_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* dvec, void* dqkv,
                                   float* dbias, float* work, int64_t N, int64_t S, int64_t num_heads, int64_t head_dim, int dtype,
                                   void* stream) {
@@ -565,16 +593,24 @@ extern "C" int pero_attention_bwd(const void* qkv, const void* out, const void* 
   if (!attr) {
     hipFuncSetAttribute((const void*)attn_bwd_dq_k, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * AT_TILE_BYTES);
     hipFuncSetAttribute((const void*)attn_bwd_dkv2_k, hipFuncAttributeMaxDynamicSharedMemorySize, AT_DKV2_LDS);
+    hipFuncSetAttribute((const void*)attn_bwd_pair_k, hipFuncAttributeMaxDynamicSharedMemorySize,
+                        AT_DKV2_LDS > 2 * AT_TILE_BYTES ? AT_DKV2_LDS : 2 * AT_TILE_BYTES);
     attr = true;
   }
   const float scale = (float)(1.0 / sqrt((double)head_dim));
   const float c = (float)(1.4426950408889634 / sqrt((double)head_dim));
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((unsigned)(N * num_heads * (S / 128))), block(256);
+  if (!out && g_attn_bwd_pair) {
+    const size_t lds = AT_DKV2_LDS > 2 * AT_TILE_BYTES ? AT_DKV2_LDS : 2 * AT_TILE_BYTES;
+    hipLaunchKernelGGL(attn_bwd_pair_k, dim3(2 * grid.x), block, lds, st, (const bf16raw*)qkv, (const bf16raw*)dout, lse, dvec, (bf16raw*)dqkv,
+                       dbias ? work : nullptr, (int)S, (int)num_heads, c, scale);
+  } else {
   hipLaunchKernelGGL(attn_bwd_dq_k, grid, block, 2 * AT_TILE_BYTES, st, (const bf16raw*)qkv, (const bf16raw*)out, (const bf16raw*)dout, lse,
                      dvec, (bf16raw*)dqkv, dbias ? work : nullptr, (int)S, (int)num_heads, c, scale);
   hipLaunchKernelGGL(attn_bwd_dkv2_k, grid, block, AT_DKV2_LDS, st, (const bf16raw*)qkv, (const bf16raw*)dout, lse, dvec,
                      (bf16raw*)dqkv, dbias ? work : nullptr, (int)S, (int)num_heads, c, scale);
+  }
   if (dbias)
     hipLaunchKernelGGL(attn_bias_reduce_k, dim3((unsigned)num_heads, 3, 16), dim3(128), 0, st, work, dbias, (int)N, (int)num_heads, (int)(S / 128));
   PERO_CHECK_LAUNCH("pero_attention_bwd");

@@ -255,6 +255,22 @@ def test_fused_attention_fwd_bwd(ops, n, s, h):
     assert torch.equal(dqkv2, dqkv)
     want = 2.0 + dqkv.float().sum(0)
     assert float((dbias - want).abs().max()) <= 1e-3 * max(1.0, float(want.abs().max()))
+    # D = rowsum(dO * O) handed in (the step takes it from the epilogue of the product that made dO): `out` is not read and both
+    # backward kernels run as ONE launch with the four workgroups of a (line, head) side by side - same numbers, bit for bit
+    # (D computed here exactly as the dQ kernel computes it: f32 products of the bf16 values, summed per head)
+    from pero_pretraining_amd._lib import call
+    dvec = (out.float() * dev(dout).float()).reshape(n * s, h, hd).sum(-1).contiguous()
+    db_pair, db_two = torch.zeros(3 * d, device="cuda"), torch.zeros(3 * d, device="cuda")
+    got_pair = ops.attention_bwd_fused(dev(qkv), None, dev(dout), lse, n, s, h, dbias=db_pair, dvec=dvec)
+    call("pero_set_option", b"attn_bwd_pair", 0)
+    try:
+        got_two = ops.attention_bwd_fused(dev(qkv), None, dev(dout), lse, n, s, h, dbias=db_two, dvec=dvec)
+    finally:
+        call("pero_set_option", b"attn_bwd_pair", 1)
+    assert torch.equal(got_pair, got_two)
+    assert float((db_pair - db_two).abs().max()) <= 1e-3 * max(1.0, float(db_two.abs().max()))
+    for name, sl in (("dq", slice(0, d)), ("dk", slice(d, 2 * d)), ("dv", slice(2 * d, 3 * d))):
+        assert rel_err(got_pair[:, sl], gref[:, sl]) < 3e-2, name
 
 
 # ------------------------------------------------------------------------------------------ row kernels
