@@ -270,12 +270,25 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p, int ks) {
   // (a global store would enter the counted vmcnt stream) -> p.gate as u64 [G][2][32] at the end of the kernel
   bool pst_on = false;
 #define E_PST(n_) if ((VAR & 64) && pst_on && wc == 0 && lane == 0) ((volatile unsigned long long*)(smem + E_RING + 8192))[wr * 32 + (n_)] = __builtin_amdgcn_s_memtime();
+  // VAR 128 (diagnostic build): s_memtime at the start of every K-tile of the workgroup's THIRD tile, at its epilogue's start and end
+  // and at the next tile's first two K-tiles (waves 0 and 4) -> p.gate as u64 [G][2][32]
+#define E_KST(n_) if ((VAR & 128) && wc == 0 && lane == 0 && (n_) < 32) ((volatile unsigned long long*)(smem + E_RING + 8192))[wr * 32 + (n_)] = __builtin_amdgcn_s_memtime();
 
-  // epilogue addressing: after the column swap a lane holds columns c8 .. c8 + 7 of a 32-column block of row li
-  const int cq = ((lq & 1) << 1) | (lq >> 1), c8 = 8 * cq;
-  const unsigned cvo = (unsigned)(((128 * wr + li) * p.ldc + 64 * wc + c8) * 2);   // C
-  const unsigned gvo = (unsigned)(((128 * wr + li) * (EPI == EP_RESID ? p.ldr : p.ldg) + 64 * wc + c8) * 2);  // residual / row-dot matrix
-  const unsigned mvo = (unsigned)((128 * wr + li) * p.ldg + 8 * wc);               // bit mask: 8 bytes per row and wave
+  // Epilogue addressing.  After the column swap lane (li, lq) holds the 8 columns 8 cq .. 8 cq + 7 of a 32-column block of row li:
+  // the four 16-byte pieces of a row sit in lanes 16 apart and ADJACENT lanes belong to different rows.  The memory pipeline merges
+  // the addresses of adjacent lanes only: stored (or loaded) like that, a 1 KiB wave-instruction is 64 separate 16-byte requests and
+  // takes 64 cycles of the CU's store path instead of 16 (tools/probe_store3.hip: 128 KiB tile 7.5 k cycles against 2.1 k, at any
+  // row pitch, with nothing else running).  So the packed values go through ONE lane transpose first (4 x ds_bpermute_b32 per unit):
+  // lane L then holds piece L & 3 of row L >> 2 and four adjacent lanes cover 64 contiguous bytes; side inputs and the bit mask are
+  // addressed in that layout as well.
+  const int cq = ((lq & 1) << 1) | (lq >> 1);
+  const int er = lane >> 2, ep = lane & 3;                                          // row and 16-byte piece of the transposed layout
+  const int tsrc = 4 * (er + 16 * (((ep & 1) << 1) | (ep >> 1)));                  // ds_bpermute address: the lane that holds (row er, piece ep)
+  const unsigned cvo = (unsigned)(((128 * wr + er) * p.ldc + 64 * wc + 8 * ep) * 2);   // C
+  const unsigned gvo = (unsigned)(((128 * wr + er) * (EPI == EP_RESID ? p.ldr : p.ldg) + 64 * wc + 8 * ep) * 2);  // residual / row-dot matrix
+  const unsigned mvo = (unsigned)((128 * wr + er) * p.ldg + 8 * wc);               // bit mask: 8 bytes per row and wave
+  auto lane_t = [&](const unsigned x) -> unsigned { return (unsigned)__builtin_amdgcn_ds_bpermute(tsrc, (int)x); };
+  (void)cq;
   eu4v side0[8], side1[8];   // side inputs of rows 0-63 / 64-127 (EP_RESID, EP_ROWDOT: 16 B per unit)
   eu2v sm0[4], sm1[4];       // EP_GATE_BITS: the 8 mask bytes of a row (this wave's 64 columns), per row group
 
@@ -306,6 +319,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p, int ks) {
       unsigned char* const kt = smem + d * E_KTILE;         // K-tile t
       unsigned char* const kn = smem + (d ^ 1) * E_KTILE;   // K-tiles t + 1 (being completed) and, slot by slot, t + 2
       if (VAR & 64) pst_on = (tix == ((VAR & 8) ? 2 : 0)) && t == (nk > 4 ? 4 : 1);
+      if ((VAR & 128) && tix == 2) { E_KST(t); }
+      if ((VAR & 128) && tix == 3 && t < 3) { E_KST(nk + 2 + t); }
       // P1
       E_PST(0);
       E_RD_B(fb0, 0);
@@ -372,10 +387,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p, int ks) {
       else if (EPI == EP_SPLITK && t + 2 >= nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stream has ended
       else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
       E_PST(13);
+      if ((VAR & 128) && last && tix == 2) { E_KST(nk + 5); }
       E_BAR();
+      if ((VAR & 128) && last && tix == 2) { E_KST(nk + 6); }
       E_PST(14);
       E_MFMA(1, 0, fb0);
       E_PST(15);
+      if ((VAR & 128) && last && tix == 2) { E_KST(nk + 7); }
       E_BAR();
       E_PST(16);
       d ^= 1;
@@ -385,8 +403,16 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p, int ks) {
 
     // ---- epilogue, straight from the accumulators
     E_STAMP(1);
+    if ((VAR & 128) && tix == 2) { E_KST(nk); }
     first = false;
     issue(nk + 1, 1, smem + (d ^ 1) * E_KTILE);  // A1 of the next tile's K-tile 1: ahead of the stores in the in-order counter
+    // Undo the stagger for the epilogue (VAR 16: keep it).  Staggered, waves 4-7 sit at the barrier behind their last MFMA
+    // cluster until waves 0-3 reach the next tile's first barrier, i.e. through the whole epilogue of waves 0-3, and waves 0-3 then
+    // sit through the epilogue of waves 4-7: the two epilogues ran one after the other (stamps at K = 512: 4.5 k + 5.3 k cycles of a
+    // 40 k-cycle tile).  With one extra barrier here waves 0-3 wait the 256 cycles of that last cluster and both epilogues run
+    // side by side; waves 4-7 take the extra barrier in front of the next tile, which staggers the groups again.
+    if (EPI != EP_SPLITK && !(VAR & 16) && wr == 0) { E_BAR(); }
+    if ((VAR & 128) && tix == 2) { E_KST(nk + 8); }
     if (EPI == EP_SPLITK) {
       // f32 tile added into C with atomics whose wave-instructions cover 256 contiguous bytes (full atomic rate): two rounds
       // through the (now free) 128 KiB ring, [128 rows][256 f32], 16-byte chunk index XORed with (row & 15)
@@ -432,6 +458,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p, int ks) {
           bx[hb][j] = (f4v){0.f, 0.f, 0.f, 0.f};
           if (use_bias) bx[hb][j] = *(const f4v*)(biasl + (64 * wc + 32 * hb + 16 * j + 4 * lq) * 4);
         }
+      if ((VAR & 128) && tix == 2) { E_KST(nk + 9); }
       float cs[2][8];  // EP_GATE_BITS + column sums
       float rd[4];     // EP_ROWDOT: row dots of one row group
 #pragma unroll
@@ -449,134 +476,151 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p, int ks) {
           }
           E_WAIT8(2 + 2 + CN::L1, side0);
         }
+        if ((VAR & 128) && tix == 2 && ha == 1) { E_KST(nk + 10); }
         if (CN::L1 && ha == 1) E_WAIT8(CN::S_HALF, side1);
         if (EPI == EP_GATE_BITS && ha == 0) {
           // retired by phase 4's wait of the last K-tile long ago (the statements tie the registers to a wait)
           E_WAIT4(63, sm0);
           E_WAIT4(63, sm1);
         }
+        // Units (row group i, B half hb) are computed NI row groups at a time, instruction kind by instruction kind: one unit's chain
+        // (add -> convert -> lane swap -> store, each waiting for the one before, and the next unit reusing the same registers)
+        // took ~190 cycles of a wave that had the SIMD to itself (stamps); independent chains side by side fill those gaps.
+        constexpr int NI = (EPI == EP_RESID || EPI == EP_ROWDOT) ? 1 : 2;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-          const int so = (64 * ha + 16 * i) * cpitch;
-          unsigned mL = 0, mH = 0;
-          if (EPI == EP_ROWDOT) rd[i] = 0.f;
+        for (int ib = 0; ib < 4; ib += NI) {
+          eu4v o[NI][2];
 #pragma unroll
-          for (int hb = 0; hb < 2; hb++) {
-            const f4v x = acc[ha][hb][i][0] + bx[hb][0], y = acc[ha][hb][i][1] + bx[hb][1];  // (alpha = 1: the other kernels' acc * alpha + bias, bit for bit)
-            eu4v o;
-            if (EPI == EP_RESID) {
-              // f32 columns first (one rounding): even lane groups keep x and take the odd neighbour's x, odd ones y
-              float v[8];
+          for (int ii = 0; ii < NI; ii++)
 #pragma unroll
-              for (int e = 0; e < 4; e++) {
-                auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(x[e]), __float_as_uint(y[e]), false, false);
-                v[e] = __uint_as_float(sw[0]); v[4 + e] = __uint_as_float(sw[1]);
+            for (int hb = 0; hb < 2; hb++) {
+              const int i = ib + ii;
+              const f4v x = acc[ha][hb][i][0] + bx[hb][0], y = acc[ha][hb][i][1] + bx[hb][1];  // (alpha = 1: the other kernels' acc * alpha + bias, bit for bit)
+              if (EPI == EP_RESID) {
+                // f32 columns first (one rounding): even lane groups keep x and take the odd neighbour's x, odd ones y
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                  auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(x[e]), __float_as_uint(y[e]), false, false);
+                  v[e] = __uint_as_float(sw[0]); v[4 + e] = __uint_as_float(sw[1]);
+                }
+#pragma unroll
+                for (int e = 0; e < 8; e++) v[e] = __uint_as_float(lane_t(__float_as_uint(v[e])));   // the f32 sums move, rounded once below
+                const eu4v r4 = ha ? side1[2 * i + hb] : side0[2 * i + hb];
+#pragma unroll
+                for (int e = 0; e < 4; e++) { v[2 * e] += __uint_as_float(r4[e] << 16); v[2 * e + 1] += __uint_as_float(r4[e] & 0xffff0000u); }
+                o[ii][hb][0] = pack2bf(v[0], v[1]); o[ii][hb][1] = pack2bf(v[2], v[3]); o[ii][hb][2] = pack2bf(v[4], v[5]); o[ii][hb][3] = pack2bf(v[6], v[7]);
+              } else {
+                float xs[4] = {x[0], x[1], x[2], x[3]}, ys[4] = {y[0], y[1], y[2], y[3]};
+                if (EPI == EP_RELU || EPI == EP_RELU_BITS) {
+#pragma unroll
+                  for (int e = 0; e < 4; e++) { xs[e] = fmaxf(xs[e], 0.f); ys[e] = fmaxf(ys[e], 0.f); }
+                }
+                const unsigned px0 = pack2bf(xs[0], xs[1]), px1 = pack2bf(xs[2], xs[3]);
+                const unsigned py0 = pack2bf(ys[0], ys[1]), py1 = pack2bf(ys[2], ys[3]);
+                auto s0 = __builtin_amdgcn_permlane16_swap(px0, py0, false, false);
+                auto s1 = __builtin_amdgcn_permlane16_swap(px1, py1, false, false);
+                o[ii][hb][0] = lane_t(s0[0]); o[ii][hb][1] = lane_t(s1[0]); o[ii][hb][2] = lane_t(s0[1]); o[ii][hb][3] = lane_t(s1[1]);
               }
-              const eu4v r4 = ha ? side1[2 * i + hb] : side0[2 * i + hb];
+            }
 #pragma unroll
-              for (int e = 0; e < 4; e++) { v[2 * e] += __uint_as_float(r4[e] << 16); v[2 * e + 1] += __uint_as_float(r4[e] & 0xffff0000u); }
-              o[0] = pack2bf(v[0], v[1]); o[1] = pack2bf(v[2], v[3]); o[2] = pack2bf(v[4], v[5]); o[3] = pack2bf(v[6], v[7]);
-            } else {
-              float xs[4] = {x[0], x[1], x[2], x[3]}, ys[4] = {y[0], y[1], y[2], y[3]};
-              if (EPI == EP_RELU || EPI == EP_RELU_BITS) {
+          for (int ii = 0; ii < NI; ii++) {
+            const int i = ib + ii;
+            const int so = (64 * ha + 16 * i) * cpitch;
+            unsigned mL = 0, mH = 0;
+            if (EPI == EP_ROWDOT) rd[i] = 0.f;
 #pragma unroll
-                for (int e = 0; e < 4; e++) { xs[e] = fmaxf(xs[e], 0.f); ys[e] = fmaxf(ys[e], 0.f); }
+            for (int hb = 0; hb < 2; hb++) {
+              eu4v& ou = o[ii][hb];
+              if (EPI == EP_RELU_BITS) {
+                // bit e = (stored column e > 0); after the ReLU every half word is +0, -0 or positive
+                unsigned z = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                  const unsigned m = (((ou[k] & 0x7fff7fffu) + 0x7fff7fffu) & 0x80008000u) >> 15;  // bit 0: low half > 0, bit 16: high half
+                  z |= m << (2 * k);
+                }
+                const unsigned byte = (z & 0x55u) | ((z >> 15) & 0xaau);
+                if (hb == 0) mL = byte << (8 * ep); else mH = byte << (8 * ep);
               }
-              const unsigned px0 = pack2bf(xs[0], xs[1]), px1 = pack2bf(xs[2], xs[3]);
-              const unsigned py0 = pack2bf(ys[0], ys[1]), py1 = pack2bf(ys[2], ys[3]);
-              auto s0 = __builtin_amdgcn_permlane16_swap(px0, py0, false, false);
-              auto s1 = __builtin_amdgcn_permlane16_swap(px1, py1, false, false);
-              o[0] = s0[0]; o[1] = s1[0]; o[2] = s0[1]; o[3] = s1[1];
+              if (EPI == EP_GATE_BITS) {
+                const eu2v mm = ha ? sm1[i] : sm0[i];
+                const unsigned byte = ((hb ? mm[1] : mm[0]) >> (8 * ep)) & 0xffu;
+                const eu4v keep = *(const eu4v*)(smem + E_LUT + byte * 16);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                  ou[k] &= keep[k];
+                  if (colsum) { cs[hb][2 * k] += __uint_as_float(ou[k] << 16); cs[hb][2 * k + 1] += __uint_as_float(ou[k] & 0xffff0000u); }
+                }
+              }
+              if (EPI == EP_ROWDOT) {
+                const eu4v g4 = ha ? side1[2 * i + hb] : side0[2 * i + hb];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                  rd[i] += __uint_as_float(ou[k] << 16) * __uint_as_float(g4[k] << 16);
+                  rd[i] += __uint_as_float(ou[k] & 0xffff0000u) * __uint_as_float(g4[k] & 0xffff0000u);
+                }
+              }
+              if (VAR & 4) {  // ablation: no stores (the values stay live)
+                asm volatile("" :: "v"(ou[0]), "v"(ou[1]), "v"(ou[2]), "v"(ou[3]));
+                if (i + hb == 0) { if (hb) E_BSTORE16(ou, cvo, crs, so, 64); else E_BSTORE16(ou, cvo, crs, so, 0); }
+              } else if (VAR & 32) {
+                if (hb) E_BSTORE16_NT(ou, cvo, crs, so, 64); else E_BSTORE16_NT(ou, cvo, crs, so, 0);
+              } else {
+                if (hb) E_BSTORE16(ou, cvo, crs, so, 64); else E_BSTORE16(ou, cvo, crs, so, 0);
+              }
             }
             if (EPI == EP_RELU_BITS) {
-              // bit e = (stored column e > 0); after the ReLU every half word is +0, -0 or positive
-              unsigned z = 0;
-#pragma unroll
-              for (int k = 0; k < 4; k++) {
-                const unsigned m = (((o[k] & 0x7fff7fffu) + 0x7fff7fffu) & 0x80008000u) >> 15;  // bit 0: low half > 0, bit 16: high half
-                z |= m << (2 * k);
-              }
-              const unsigned byte = (z & 0x55u) | ((z >> 15) & 0xaau);
-              if (hb == 0) mL = byte << (8 * cq); else mH = byte << (8 * cq);
-            }
-            if (EPI == EP_GATE_BITS) {
-              const eu2v mm = ha ? sm1[i] : sm0[i];
-              const unsigned byte = ((hb ? mm[1] : mm[0]) >> (8 * cq)) & 0xffu;
-              const eu4v keep = *(const eu4v*)(smem + E_LUT + byte * 16);
-#pragma unroll
-              for (int k = 0; k < 4; k++) {
-                o[k] &= keep[k];
-                if (colsum) { cs[hb][2 * k] += __uint_as_float(o[k] << 16); cs[hb][2 * k + 1] += __uint_as_float(o[k] & 0xffff0000u); }
-              }
+              // OR over the four lanes of a row (one quad): every one of them then holds the row's 8 bytes
+              mL |= (unsigned)__builtin_amdgcn_mov_dpp((int)mL, 0xB1, 0xf, 0xf, false);  // quad_perm [1,0,3,2]
+              mH |= (unsigned)__builtin_amdgcn_mov_dpp((int)mH, 0xB1, 0xf, 0xf, false);
+              mL |= (unsigned)__builtin_amdgcn_mov_dpp((int)mL, 0x4E, 0xf, 0xf, false);  // quad_perm [2,3,0,1]
+              mH |= (unsigned)__builtin_amdgcn_mov_dpp((int)mH, 0x4E, 0xf, 0xf, false);
+              const eu2v mo = {mL, mH};
+              const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc((unsigned char*)p.gate + tm0 * p.ldg + (tn0 >> 3), 0, (int)(256 * p.ldg), 0x00020000);
+              // all four store them (same address, same data): one instruction, no branch
+              __builtin_amdgcn_raw_buffer_store_b64(mo, mrs, mvo, (64 * ha + 16 * i) * (int)p.ldg, 0);
             }
             if (EPI == EP_ROWDOT) {
-              const eu4v g4 = ha ? side1[2 * i + hb] : side0[2 * i + hb];
-#pragma unroll
-              for (int k = 0; k < 4; k++) {
-                rd[i] += __uint_as_float(o[k] << 16) * __uint_as_float(g4[k] << 16);
-                rd[i] += __uint_as_float(o[k] & 0xffff0000u) * __uint_as_float(g4[k] & 0xffff0000u);
-              }
+              // sum over the four lanes of a row (one quad), then its first lane adds into [m][n / 128] (two waves per 128-column block)
+              float s = rd[i];
+              s += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s), 0xB1, 0xf, 0xf, false));
+              s += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s), 0x4E, 0xf, 0xf, false));
+              float* dst = (float*)p.bias + (tm0 + 128 * wr + 64 * ha + 16 * i + er) * (p.N >> 7) + ((tn0 + 64 * wc) >> 7);
+              if (ep == 0) atomicAdd(dst, s);
             }
-            if (VAR & 4) {  // ablation: no stores (the values stay live)
-              asm volatile("" :: "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]));
-              if (i + hb == 0) { if (hb) E_BSTORE16(o, cvo, crs, so, 64); else E_BSTORE16(o, cvo, crs, so, 0); }
-            } else if (VAR & 32) {
-              if (hb) E_BSTORE16_NT(o, cvo, crs, so, 64); else E_BSTORE16_NT(o, cvo, crs, so, 0);
-            } else {
-              if (hb) E_BSTORE16(o, cvo, crs, so, 64); else E_BSTORE16(o, cvo, crs, so, 0);
-            }
-          }
-          if (EPI == EP_RELU_BITS) {
-            // OR over the four lanes of a row (lane, lane ^ 16, lane ^ 32, lane ^ 48): every one of them then holds the row's 8 bytes
-            auto a = __builtin_amdgcn_permlane32_swap(mL, mL, false, false); mL = a[0] | a[1];
-            auto b = __builtin_amdgcn_permlane32_swap(mH, mH, false, false); mH = b[0] | b[1];
-            auto c = __builtin_amdgcn_permlane16_swap(mL, mL, false, false); mL = c[0] | c[1];
-            auto e2 = __builtin_amdgcn_permlane16_swap(mH, mH, false, false); mH = e2[0] | e2[1];
-            const eu2v mo = {mL, mH};
-            const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc((unsigned char*)p.gate + tm0 * p.ldg + (tn0 >> 3), 0, (int)(256 * p.ldg), 0x00020000);
-            // all four store them (same address, same data): one instruction, no branch
-            __builtin_amdgcn_raw_buffer_store_b64(mo, mrs, mvo, (64 * ha + 16 * i) * (int)p.ldg, 0);
-          }
-          if (EPI == EP_ROWDOT) {
-            // sum over the four lanes of a row, then lane group 0 adds into [m][n / 128] (two waves per 128-column block)
-            float s = rd[i];
-            auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
-            s = __uint_as_float(a[0]) + __uint_as_float(a[1]);
-            auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(s), __float_as_uint(s), false, false);
-            s = __uint_as_float(b[0]) + __uint_as_float(b[1]);
-            float* dst = (float*)p.bias + (tm0 + 128 * wr + 64 * ha + 16 * i + li) * (p.N >> 7) + ((tn0 + 64 * wc) >> 7);
-            if (lq == 0) atomicAdd(dst, s);
           }
         }
       }
       if (colsum) {
         // column sums of the tile's 128 rows of this wave.  A lane holds 16 partial sums (its 8 columns x 2 B halves) of its
-        // row; a halving butterfly over the 16 rows of the lane group (xor 8, 4, 2, 1: each step a lane keeps half of its
-        // values and adds the partner's copy of them - 15 exchanges instead of 64) leaves the total of value `li` on lane li,
+        // rows; a halving butterfly over the 16 row indices of the wave (lane bits 2-5: xor 32, 16, 8, 4; each step a lane keeps half of
+        // its values and adds the partner's copy of them - 15 exchanges instead of 64) leaves the total of value `er` on the lane,
         // and ONE atomic instruction with all 64 lanes adds the wave's 64 column sums
         float w8[8], w4[4], w2[2];
 #pragma unroll
         for (int j = 0; j < 8; j++) {
           const float a = cs[0][j], b2 = cs[1][j];
-          const float send = (li & 8) ? a : b2, keepv = (li & 8) ? b2 : a;
-          w8[j] = keepv + __shfl_xor(send, 8, 64);
+          const float send = (er & 8) ? a : b2, keepv = (er & 8) ? b2 : a;
+          w8[j] = keepv + __shfl_xor(send, 32, 64);
         }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-          const float send = (li & 4) ? w8[j] : w8[j + 4], keepv = (li & 4) ? w8[j + 4] : w8[j];
-          w4[j] = keepv + __shfl_xor(send, 4, 64);
+          const float send = (er & 4) ? w8[j] : w8[j + 4], keepv = (er & 4) ? w8[j + 4] : w8[j];
+          w4[j] = keepv + __shfl_xor(send, 16, 64);
         }
 #pragma unroll
         for (int j = 0; j < 2; j++) {
-          const float send = (li & 2) ? w4[j] : w4[j + 2], keepv = (li & 2) ? w4[j + 2] : w4[j];
-          w2[j] = keepv + __shfl_xor(send, 2, 64);
+          const float send = (er & 2) ? w4[j] : w4[j + 2], keepv = (er & 2) ? w4[j + 2] : w4[j];
+          w2[j] = keepv + __shfl_xor(send, 8, 64);
         }
-        const float send = (li & 1) ? w2[0] : w2[1], keepv = (li & 1) ? w2[1] : w2[0];
-        const float tot = keepv + __shfl_xor(send, 1, 64);     // value index li = 8 * hb + e
-        atomicAdd((float*)p.bias + tn0 + 64 * wc + 32 * (li >> 3) + c8 + (li & 7), tot);
+        const float send = (er & 1) ? w2[0] : w2[1], keepv = (er & 1) ? w2[1] : w2[0];
+        const float tot = keepv + __shfl_xor(send, 4, 64);     // value index er = 8 * hb + e, of the lane's piece ep
+        atomicAdd((float*)p.bias + tn0 + 64 * wc + 32 * (er >> 3) + 8 * ep + (er & 7), tot);
       }
     }
     E_STAMP(2);
+    if ((VAR & 128) && tix == 2) { E_KST(nk + 1); }
     tix++;
     if (!has_next) break;
     T += G;
@@ -585,11 +629,14 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p, int ks) {
     tile_of(has_next ? T + G : T, nm0, nn0);
     nA = (const unsigned char*)A + nm0 * sa.tile;
     nB = (const unsigned char*)B + nn0 * sb.tile;
+    if (!(VAR & 16) && wr == 1) { E_BAR(); }  // the stagger again
   }
   if ((VAR & 64) && wc == 0 && lane < 17)
     ((unsigned long long*)p.gate)[(VAR & 8 ? (size_t)gridDim.x * 2 * 64 * 4 : 0) + ((size_t)blockIdx.x * 2 + wr) * 32 + lane] = ((unsigned long long*)(smem + E_RING + 8192))[wr * 32 + lane];
+  if ((VAR & 128) && wc == 0 && lane < 32)
+    ((unsigned long long*)p.gate)[((size_t)blockIdx.x * 2 + wr) * 32 + lane] = ((unsigned long long*)(smem + E_RING + 8192))[wr * 32 + lane];
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last tile's surplus prefetches land before the LDS is released
-  if (wr == 0) { E_BAR(); }  // balance the stagger barrier
+  if ((VAR & 16) && wr == 0) { E_BAR(); }  // balance the stagger barrier (otherwise the last epilogue's extra barrier has done it)
 #undef E_RD_A
 #undef E_RD_B
 #undef E_MFMA
@@ -603,6 +650,8 @@ int g_gemm_e_var = 0;
 bool pero_launch_gemm_e256(const GemmP& p0, long long batch, int k_split, bool ta, bool tb, bool out_f32, hipStream_t st, int var) {
   if (p0.M % E_BM || p0.N % E_BN || p0.K % E_BK || p0.K < 2 * E_BK || batch != 1) return false;
   if (var < 0) var = g_gemm_e_var;
+  const int wg_cap = ((var >> 8) & 0xff) * 8;  // diagnostic: at most this many workgroups (bits 8-15 of the variant, in units of 8)
+  var &= 0xff;
   int ks = 0;
   if (p0.flags & PERO_GEMM_ATOMIC) {
     // split-K: f32 C, plain product, equal slices of whole K-tiles, one slice set per XCD
@@ -652,7 +701,7 @@ bool pero_launch_gemm_e256(const GemmP& p0, long long batch, int k_split, bool t
   const bool relu = p0.flags & PERO_GEMM_RELU, bits = p0.flags & PERO_GEMM_RELU_BITS, rowdot = p0.flags & PERO_GEMM_ROWDOT,
              cs = p0.flags & PERO_GEMM_COLSUM;
   int epi;
-  if (var & 8) epi = EP_PLAIN;                       // stamp build: `gate` is the stamp buffer
+  if (var & (8 | 128)) epi = EP_PLAIN;               // stamp builds: `gate` is the stamp buffer
   else if (rowdot) { if (relu || bits || cs || p0.resid || !p0.gate || !p0.bias) return false; epi = EP_ROWDOT; }
   else if (bits) { if (!p0.gate || p0.resid || (relu && cs)) return false; epi = relu ? EP_RELU_BITS : EP_GATE_BITS; }
   else if (cs || p0.gate) return false;              // column sums without the bit mask, bf16 gate rows: other kernels
@@ -670,7 +719,8 @@ bool pero_launch_gemm_e256(const GemmP& p0, long long batch, int k_split, bool t
   GemmP p = p0;
   p.kchunk = p.K;
   const long long nt = (p.M / E_BM) * (p.N / E_BN);
-  const unsigned G = (unsigned)(nt < num_cus ? ((nt + 7) / 8) * 8 : num_cus);
+  unsigned G = (unsigned)(nt < num_cus ? ((nt + 7) / 8) * 8 : num_cus);
+  if (wg_cap && (unsigned)wg_cap < G) G = (unsigned)wg_cap;
   dim3 grid(G), block(512);
   if (epi == EP_ROWDOT) hipMemsetAsync((void*)p.bias, 0, (size_t)p.M * (size_t)(p.N >> 7) * sizeof(float), st);  // the two waves of a 128-column block add into it
 #define LAUNCH_E(TA_, TB_, EP_, VAR_)                                                                                            \
@@ -685,7 +735,7 @@ bool pero_launch_gemm_e256(const GemmP& p0, long long batch, int k_split, bool t
   if (!ta && !tb) {
     switch (epi) {
       case EP_RELU: LAUNCH_E(false, false, EP_RELU, 0); break;
-      case EP_RESID: if (var == 2) LAUNCH_E(false, false, EP_RESID, 2); else LAUNCH_E(false, false, EP_RESID, 0); break;
+      case EP_RESID: if (var == 2) LAUNCH_E(false, false, EP_RESID, 2); else if (var == 16) LAUNCH_E(false, false, EP_RESID, 16); else LAUNCH_E(false, false, EP_RESID, 0); break;
       case EP_RELU_BITS: LAUNCH_E(false, false, EP_RELU_BITS, 0); break;
       case EP_GATE_BITS: LAUNCH_E(false, false, EP_GATE_BITS, 0); break;
       case EP_ROWDOT: LAUNCH_E(false, false, EP_ROWDOT, 0); break;
@@ -696,8 +746,11 @@ bool pero_launch_gemm_e256(const GemmP& p0, long long batch, int k_split, bool t
           case 8: LAUNCH_E(false, false, EP_PLAIN, 8); break;
           case 10: LAUNCH_E(false, false, EP_PLAIN, 10); break;
           case 12: LAUNCH_E(false, false, EP_PLAIN, 12); break;
+          case 16: LAUNCH_E(false, false, EP_PLAIN, 16); break;
           case 32: LAUNCH_E(false, false, EP_PLAIN, 32); break;
           case 72: LAUNCH_E(false, false, EP_PLAIN, 72); break;
+          case 128: LAUNCH_E(false, false, EP_PLAIN, 128); break;
+          case 132: LAUNCH_E(false, false, EP_PLAIN, 132); break;
           default: LAUNCH_E(false, false, EP_PLAIN, 0); break;
         }
     }

@@ -107,6 +107,24 @@ for _ in range(10):
     nd += int((ops.gemm(x, w) != y0).sum())
 print(f"  10 repeats: {nd} differing outputs", flush=True)
 fails += nd != 0
+# the same with bias + ReLU + bit mask (a tile's epilogue runs inside the next tile's first K-tile)
+bias = torch.randn(1536, device="cuda")
+bits = torch.zeros((131072, 1536 // 8), device="cuda", dtype=torch.uint8)
+yb = ops.gemm(x, w, bias=bias, relu=True, relu_bits=bits)
+for lo in (0, 65536 - 2048, 131072 - 4096):
+    ref = torch.relu(x[lo:lo + 4096].float() @ w.float().t() + bias)
+    fails += check(f"NT+bias+relu+bits 131072x1536x512 (rows {lo}..)", yb[lo:lo + 4096], ref)
+want = torch.from_numpy(__import__("numpy").packbits((yb > 0).cpu().numpy(), axis=1, bitorder="little")).cuda()
+nb = int((want != bits).sum())
+print(f"  bit mask: {nb} differing bytes {'FAIL' if nb else 'ok'}", flush=True)
+fails += nb != 0
+setpol(7)
+y7 = ops.gemm(x, w, bias=bias, relu=True)
+setpol(100)
+nd = int((ops.gemm(x, w, bias=bias, relu=True) != y7).sum()) + int((yb != y7).sum())
+print(f"  vs policy 7 (r256), bias + ReLU: {nd} differing outputs", flush=True)
+fails += nd != 0
+del bias, bits, yb, y7, want
 del x, w, y0
 print("CHECK", "FAILED" if fails else "PASSED", flush=True)
 if "--no-check" in sys.argv:
