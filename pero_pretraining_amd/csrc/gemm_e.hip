@@ -398,7 +398,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p, int ks) {
       E_PST(16);
       d ^= 1;
     };
-    for (int t = 0; t < nk - 1; t++) ktile(std::false_type{}, t);
+    // (the first K-tile is its own copy of the code: its MFMAs take the zero accumulators as an inline constant, so the 128 registers
+    //  are never cleared by moves, and its t == 0 cases fold)
+    ktile(std::false_type{}, 0);
+    for (int t = 1; t < nk - 1; t++) ktile(std::false_type{}, t);
     ktile(std::true_type{}, nk - 1);
 
     // ---- epilogue, straight from the accumulators
