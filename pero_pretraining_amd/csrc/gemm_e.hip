@@ -704,7 +704,8 @@ bool pero_launch_gemm_e256(const GemmP& p0, long long batch, int k_split, bool t
   const bool relu = p0.flags & PERO_GEMM_RELU, bits = p0.flags & PERO_GEMM_RELU_BITS, rowdot = p0.flags & PERO_GEMM_ROWDOT,
              cs = p0.flags & PERO_GEMM_COLSUM;
   int epi;
-  if (var & (8 | 128)) epi = EP_PLAIN;               // stamp builds: `gate` is the stamp buffer
+  if ((var & 128) && p0.resid && !relu && !bits && !rowdot && !cs) epi = EP_RESID;   // stamp build of the residual epilogue
+  else if (var & (8 | 128)) epi = EP_PLAIN;          // stamp builds: `gate` is the stamp buffer
   else if (rowdot) { if (relu || bits || cs || p0.resid || !p0.gate || !p0.bias) return false; epi = EP_ROWDOT; }
   else if (bits) { if (!p0.gate || p0.resid || (relu && cs)) return false; epi = relu ? EP_RELU_BITS : EP_GATE_BITS; }
   else if (cs || p0.gate) return false;              // column sums without the bit mask, bf16 gate rows: other kernels
@@ -738,7 +739,7 @@ bool pero_launch_gemm_e256(const GemmP& p0, long long batch, int k_split, bool t
   if (!ta && !tb) {
     switch (epi) {
       case EP_RELU: LAUNCH_E(false, false, EP_RELU, 0); break;
-      case EP_RESID: if (var == 2) LAUNCH_E(false, false, EP_RESID, 2); else if (var == 16) LAUNCH_E(false, false, EP_RESID, 16); else LAUNCH_E(false, false, EP_RESID, 0); break;
+      case EP_RESID: if (var == 128) LAUNCH_E(false, false, EP_RESID, 128); else if (var == 2) LAUNCH_E(false, false, EP_RESID, 2); else if (var == 16) LAUNCH_E(false, false, EP_RESID, 16); else LAUNCH_E(false, false, EP_RESID, 0); break;
       case EP_RELU_BITS: LAUNCH_E(false, false, EP_RELU_BITS, 0); break;
       case EP_GATE_BITS: LAUNCH_E(false, false, EP_GATE_BITS, 0); break;
       case EP_ROWDOT: LAUNCH_E(false, false, EP_ROWDOT, 0); break;

@@ -83,6 +83,69 @@ __global__ __launch_bounds__(256) void layernorm_fwd_k(const T* x, const float* 
   }
 }
 
+// bf16, d <= 512 (one 8-column group per lane), no positional table: the arithmetic of layernorm_fwd_k<bf16raw, 1>, FOUR rows per wave
+// with their loads issued together (the one-row-per-wave form is 65 536 workgroups of four short-lived waves at M = 262 144:
+// 4.9 TB/s; four rows in flight per wave and a quarter of the waves: see DESIGN section 8.1).
+__global__ __launch_bounds__(256) void layernorm_fwd4_k(const bf16raw* x, const float* gamma, const float* beta, bf16raw* y, float* mean,
+                                                        float* rstd, long long rows, int d, float eps) {
+  const int lane = threadIdx.x & 63;
+  const long long row0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
+  if (row0 >= rows) return;
+  const int col = lane * 8;
+  const bool act = col < d;
+  uint4 raw[4];
+#pragma unroll
+  for (int u = 0; u < 4; u++) {
+    raw[u] = make_uint4(0, 0, 0, 0);
+    if (act && row0 + u < rows) raw[u] = *(const uint4*)(x + (row0 + u) * d + col);
+  }
+  float g[8], b[8];
+#pragma unroll
+  for (int e = 0; e < 8; e++) { g[e] = 0.f; b[e] = 0.f; }
+  if (act) { load8<float>(gamma + col, g); load8<float>(beta + col, b); }
+  float v[4][8], s[4];
+#pragma unroll
+  for (int u = 0; u < 4; u++) {
+    const unsigned w[4] = {raw[u].x, raw[u].y, raw[u].z, raw[u].w};
+    s[u] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      v[u][e] = (e & 1) ? __uint_as_float(w[e >> 1] & 0xffff0000u) : __uint_as_float(w[e >> 1] << 16);
+      if (act) s[u] += v[u][e];
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+    for (int u = 0; u < 4; u++) s[u] += __shfl_xor(s[u], o, 64);
+  float mu[4], q[4];
+#pragma unroll
+  for (int u = 0; u < 4; u++) {
+    mu[u] = s[u] / (float)d;
+    q[u] = 0.f;
+    if (act) {
+#pragma unroll
+      for (int e = 0; e < 8; e++) { const float t = v[u][e] - mu[u]; q[u] += t * t; }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+    for (int u = 0; u < 4; u++) q[u] += __shfl_xor(q[u], o, 64);
+#pragma unroll
+  for (int u = 0; u < 4; u++) {
+    if (row0 + u >= rows) break;
+    const float rs = 1.0f / sqrtf(q[u] / (float)d + eps);
+    if (lane == 0) { mean[row0 + u] = mu[u]; rstd[row0 + u] = rs; }
+    if (act) {
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; e++) o[e] = (v[u][e] - mu[u]) * rs * g[e] + b[e];
+      store8<bf16raw>(y + (row0 + u) * d + col, o);
+    }
+  }
+}
+
 // LayerNorm backward: dx per row; dgamma / dbeta / column sums of dx accumulated per lane over the rows
 // a wave visits, combined across the block's 4 waves through LDS, then one f32 atomic per column.
 template <typename T, int NCH>
@@ -281,7 +344,10 @@ static int ln_dispatch_fwd(const void* x, const float* gamma, const float* beta,
   dim3 grid((unsigned)((rows + 3) / 4)), block(256);
   const int nch = (int)((d + 511) / 512);
 #define LN_F(N_) hipLaunchKernelGGL((layernorm_fwd_k<T, N_>), grid, block, 0, st, (const T*)x, gamma, beta, pe, offsets, (T*)y, mean, rstd, (long long)rows, (int)d, (long long)S, eps)
-  if (nch == 1) LN_F(1); else if (nch == 2) LN_F(2); else if (nch <= 4) LN_F(4); else LN_F(8);
+  if (nch == 1 && sizeof(T) == 2 && !pe && rows >= 4096)
+    hipLaunchKernelGGL(layernorm_fwd4_k, dim3((unsigned)((rows + 15) / 16)), block, 0, st, (const bf16raw*)x, gamma, beta, (bf16raw*)y, mean, rstd,
+                       (long long)rows, (int)d, eps);
+  else if (nch == 1) LN_F(1); else if (nch == 2) LN_F(2); else if (nch <= 4) LN_F(4); else LN_F(8);
 #undef LN_F
   return 0;
 }

@@ -303,6 +303,21 @@ def test_layernorm_fwd_bwd(ops, dtype, rows, d):
     assert rel_err(dxs, xr.grad.sum(0)) < 1e-4  # column sums are taken in f32 before dx is rounded
 
 
+@pytest.mark.parametrize("rows,d", [(4096 + 13, 512), (8192, 256), (5000, 504)])
+def test_layernorm_fwd_four_rows_per_wave_equals_one_row_per_wave(ops, rows, d):
+    """bf16, d <= 512, >= 4096 rows, no positional table: the four-rows-per-wave kernel - the rows, means and rstds it writes are those
+    of the one-row-per-wave kernel (which a call on < 4096 rows takes), bit for bit; and they match the oracle."""
+    g = torch.Generator().manual_seed(rows + d)
+    x = dev((torch.randn(rows, d, generator=g) * 2 + 0.3).bfloat16())
+    gamma, beta = dev(torch.randn(d, generator=g)), dev(torch.randn(d, generator=g))
+    y, mean, rstd = ops.layernorm_fwd(x, gamma, beta, 1e-5)
+    for lo in range(0, rows, 4000):   # chunks below the threshold
+        y1, m1, r1 = ops.layernorm_fwd(x[lo:lo + 4000].contiguous(), gamma, beta, 1e-5)
+        assert torch.equal(y[lo:lo + 4000], y1) and torch.equal(mean[lo:lo + 4000], m1) and torch.equal(rstd[lo:lo + 4000], r1)
+    y_ref = O.layer_norm(x.float().cpu(), gamma.cpu(), beta.cpu())
+    assert rel_err(y, y_ref) < 2 ** -7
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_softmax_fwd_bwd(ops, dtype):
     g = torch.Generator().manual_seed(1)

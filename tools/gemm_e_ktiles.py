@@ -8,18 +8,25 @@ from pero_pretraining_amd import ops, _lib
 torch.manual_seed(0)
 L = _lib.lib()
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
+RES = "--res" in sys.argv   # the residual epilogue
+sys.argv = [a for a in sys.argv if a != "--res"]
 VARX = int(sys.argv[3]) if len(sys.argv) > 3 else 0   # extra variant bits (4: the epilogue without its stores)
 CAP = int(sys.argv[2]) if len(sys.argv) > 2 else 0   # at most this many workgroups (multiple of 8): fewer CUs share the memory system
-for (N, K) in [(1536, 512), (2048, 512)]:
+for (N, K) in ([(512, 512), (512, 2048)] if RES else [(1536, 512), (2048, 512)]):
     x = (torch.randn(M, K, device="cuda") * 0.5).bfloat16()
     w = (torch.randn(N, K, device="cuda") * 0.5).bfloat16()
     bias = torch.randn(N, device="cuda")
     y = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    res = torch.randn(M, N, device="cuda").bfloat16()
     G = 256
     st = torch.zeros(G * 2 * 32, device="cuda", dtype=torch.int64)
     L.pero_set_option(b"gemm_policy", 20); L.pero_set_option(b"gemm_e_var", 128 | VARX | ((CAP // 8) << 8))
     for _ in range(5):
-        ops.gemm(x, w, out=y, bias=bias, gate=st.view(torch.bfloat16).view(-1, 8))
+        if RES:
+            ops.gemm_raw(x, w, y, M, N, K, K, K, N, bias=bias, residual=res, ldr=N, gate=st, ldg=8, flags=0,
+                         in_dtype=_lib.PERO_BF16, out_dtype=_lib.PERO_BF16)
+        else:
+            ops.gemm(x, w, out=y, bias=bias, gate=st.view(torch.bfloat16).view(-1, 8))
     torch.cuda.synchronize()
     nk = K // 64
     ph = st.view(G, 2, 32)[:CAP or G].cpu().double()
