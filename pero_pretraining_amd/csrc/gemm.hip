@@ -475,7 +475,7 @@ static int gemm_dispatch(const void* A, const void* B, void* C, const float* bia
       PERO_CHECK_LAUNCH("pero_gemm(e256)");
       return PERO_OK;
     }
-    PERO_REQUIRE(!(g_gemm_policy == 20 && (g_gemm_e_var & (8 | 64))), "pero_gemm: the stamp build did not take this product");  // its `gate` is a debug buffer
+    PERO_REQUIRE(!(g_gemm_policy == 20 && (g_gemm_e_var & (8 | 64 | 128))), "pero_gemm: the stamp build did not take this product");  // its `gate` is a debug buffer
     if (atomic && k_split == 0) {
       long long ks = (g_splitk_items + t128 - 1) / t128;
       if (ks > K / 512) ks = K / 512;

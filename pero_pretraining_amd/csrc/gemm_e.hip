@@ -319,7 +319,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p, int ks) {
       unsigned char* const kt = smem + d * E_KTILE;         // K-tile t
       unsigned char* const kn = smem + (d ^ 1) * E_KTILE;   // K-tiles t + 1 (being completed) and, slot by slot, t + 2
       if (VAR & 64) pst_on = (tix == ((VAR & 8) ? 2 : 0)) && t == (nk > 4 ? 4 : 1);
-      if ((VAR & 128) && tix == 2) { E_KST(t); }
+      if ((VAR & 128) && (tix == 2 || EPI == EP_SPLITK)) { E_KST(t); }
       if ((VAR & 128) && tix == 3 && t < 3) { E_KST(nk + 2 + t); }
       // P1
       E_PST(0);
@@ -421,6 +421,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p, int ks) {
       // through the (now free) 128 KiB ring, [128 rows][256 f32], 16-byte chunk index XORed with (row & 15)
       if (wr == 0) { E_BAR(); }  // undo the stagger: every wave has finished its last reads and MFMAs
       if ((VAR & 64) && wc == 0 && lane < 17)
+        ((unsigned long long*)p.gate)[((size_t)blockIdx.x * 2 + wr) * 32 + lane] = ((unsigned long long*)(smem + E_RING + 8192))[wr * 32 + lane];
+      if ((VAR & 128) && wc == 0 && lane < 32)
         ((unsigned long long*)p.gate)[((size_t)blockIdx.x * 2 + wr) * 32 + lane] = ((unsigned long long*)(smem + E_RING + 8192))[wr * 32 + lane];
       float* const C = (float*)p.C;
 #pragma unroll
@@ -658,7 +660,7 @@ bool pero_launch_gemm_e256(const GemmP& p0, long long batch, int k_split, bool t
   int ks = 0;
   if (p0.flags & PERO_GEMM_ATOMIC) {
     // split-K: f32 C, plain product, equal slices of whole K-tiles, one slice set per XCD
-    if (!out_f32 || p0.bias || p0.resid || (p0.gate && !(var & 64)) || (p0.flags & ~(PERO_GEMM_ATOMIC | PERO_GEMM_TRANS_A | PERO_GEMM_TRANS_B | PERO_GEMM_TILE_V | PERO_GEMM_TILE256))) return false;
+    if (!out_f32 || p0.bias || p0.resid || (p0.gate && !(var & (64 | 128))) || (p0.flags & ~(PERO_GEMM_ATOMIC | PERO_GEMM_TRANS_A | PERO_GEMM_TRANS_B | PERO_GEMM_TILE_V | PERO_GEMM_TILE256))) return false;
     const long long tiles = (p0.M / E_BM) * (p0.N / E_BN), steps = p0.K / E_BK;
     ks = k_split;
     if (ks <= 0) {  // the library chooses: one round of workgroups over the CUs
@@ -688,6 +690,12 @@ bool pero_launch_gemm_e256(const GemmP& p0, long long batch, int k_split, bool t
     }                                                                                                                      \
     hipLaunchKernelGGL((gemm_bf16_e256<TA_, TB_, EP_SPLITK, 0>), grid, block, E_LDS_BYTES, st, p, ks);                    \
   } while (0)
+    if ((var & 128) && ta && tb) {
+      static bool attr128 = false;
+      if (!attr128) { hipFuncSetAttribute((const void*)gemm_bf16_e256<true, true, EP_SPLITK, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, E_LDS_BYTES); attr128 = true; }
+      hipLaunchKernelGGL((gemm_bf16_e256<true, true, EP_SPLITK, 128>), grid, block, E_LDS_BYTES, st, p, ks);
+      return true;
+    }
     if ((var & 64) && ta && tb) {
       static bool attr64 = false;
       if (!attr64) { hipFuncSetAttribute((const void*)gemm_bf16_e256<true, true, EP_SPLITK, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, E_LDS_BYTES); attr64 = true; }

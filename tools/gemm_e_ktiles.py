@@ -42,3 +42,22 @@ for (N, K) in ([(512, 512), (512, 2048)] if RES else [(1536, 512), (2048, 512)])
               "epilogue start %.0f, after the extra barrier %.0f, bias in registers %.0f, rows 0-63 stored %.0f, epilogue end %.0f, next tile K-tile 0 %.0f, K-tile 1 %.0f" % tuple(
                   float(rel[wv, i]) for i in (nk - 1, nk + 5, nk + 6, nk + 7, nk, nk + 8, nk + 9, nk + 10, nk + 1, nk + 2, nk + 3)), flush=True)
 L.pero_set_option(b"gemm_e_var", 0); L.pero_set_option(b"gemm_policy", 0)
+# split-K weight gradients (TT): the first 31 K-tiles of every work item
+if "--tt" in sys.argv or True:
+    L.pero_set_option(b"gemm_policy", 0); L.pero_set_option(b"gemm_e_var", 128)
+    Mt = 262144
+    for (N, K) in [(2048, 512), (1536, 512)]:
+        x = (torch.randn(Mt, K, device="cuda") * 0.5).bfloat16()
+        dy = (torch.randn(Mt, N, device="cuda") * 0.5).bfloat16()
+        dw = torch.zeros(N, K, device="cuda")
+        st = torch.zeros(256 * 2 * 32, device="cuda", dtype=torch.int64)
+        for _ in range(5):
+            ops.gemm_raw(dy, x, dw, N, K, Mt, N, K, K, gate=st, ldg=8, flags=_lib.GEMM_TRANS_A | _lib.GEMM_TRANS_B | _lib.GEMM_ATOMIC, k_split=0,
+                         in_dtype=_lib.PERO_BF16, out_dtype=_lib.PERO_F32)
+        torch.cuda.synchronize()
+        ph = st.view(256, 2, 32).cpu().double()
+        nwg = int((ph[:, 0, 1] != 0).sum())
+        d = (ph[:nwg, :, 1:32] - ph[:nwg, :, 0:31]).median(dim=0).values
+        for wv in range(2):
+            print(f"TT dW [{N}x{K}] over {Mt} ({nwg} workgroups) wave {4 * wv}: K-tiles " + " ".join(f"{float(v):.0f}" for v in d[wv]), flush=True)
+    L.pero_set_option(b"gemm_e_var", 0)
