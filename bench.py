@@ -239,6 +239,13 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    # Under torch.distributed.run RCCL prints a version banner on the C-level stdout at communicator creation: everything but the ONE
+    # JSON line goes to stderr (file descriptor 1 is pointed at stderr; the line is written to the saved descriptor at the end)
+    real_stdout = None
+    if "RANK" in os.environ:
+        sys.stdout.flush()
+        real_stdout = os.dup(1)
+        os.dup2(2, 1)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
@@ -397,7 +404,11 @@ def main():
             "final_loss": round(final_loss, 5),
             "roofline": roofline, "cpu_baseline": cpu, "with_prepare_batch": with_prepare, "option_masked_head": option, "legs": legs,
         }
-        print(json.dumps(out))
+        if real_stdout is None:
+            print(json.dumps(out))
+        else:
+            sys.stdout.flush()
+            os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist.is_initialized():
         dist.destroy_process_group()
 

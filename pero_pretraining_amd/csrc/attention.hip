@@ -146,10 +146,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_k(const bf16raw* qkv, bf16raw
     ps += __shfl_xor(ps, 32, 64);
     l = l * alpha + ps;
     m = mn;
+    if (kt != 0) {  // (a head's first tile: O is still zero)
 #pragma unroll
-    for (int t = 0; t < 4; t++)
+      for (int t = 0; t < 4; t++)
 #pragma unroll
-      for (int e = 0; e < 16; e++) o[t][e] *= alpha;
+        for (int e = 0; e < 16; e++) o[t][e] *= alpha;
+    }
 
     // ---- O^T += V^T P^T
 #pragma unroll
