@@ -19,14 +19,20 @@
 //    stream, so the pipeline never refills.  vmcnt is ONE in-order counter for LDS-DMA, loads and stores: the last
 //    half tile the next tile needs before its second K-tile (A1 of K-tile 1) is issued AHEAD of the epilogue's stores, and
 //    the first K-tile's wait counts them out - the stores then have two K-tiles of main loop to drain.
-//  * Epilogue straight from the accumulators (no LDS, no barrier): operands are swapped in the MFMA so that a lane owns 4
-//    consecutive output columns of one row; v_permlane16_swap between the two 16 x 16 tiles of a 32-column block gives it 8
-//    consecutive columns -> one 16-byte store (64 contiguous bytes per row and instruction).  The bias comes from a per-wave
-//    1 KiB LDS copy of the tile's bias row, fetched by one more LDS-DMA of the same stream at the tile's start (an
-//    ordinary load would have to wait for every LDS-DMA issued before it) and added in f32 before the rounding, exactly as
-//    the other tile kernels do (acc * alpha + bias): results are bit-identical across kernels, i.e. across batch sizes.  Side inputs (residual rows, the second matrix
-//    of the row dots, the ReLU bit mask) are fetched by inline-asm buffer loads the compiler does not count: half of them
-//    in phase 4 of the tile's last K-tile, half at the start of the epilogue, each waited for by a counted vmcnt.
+//  * Epilogue straight from the accumulators (no LDS memory): operands are swapped in the MFMA so that a lane owns 4 consecutive
+//    output columns of one row; v_permlane16_swap between the two 16 x 16 tiles of a 32-column block gives it 8 consecutive
+//    columns (16 bytes), and ONE lane transpose (4 x ds_bpermute_b32) moves the four 16-byte pieces of a row from lanes 16 apart
+//    onto four ADJACENT lanes before the store: the memory pipeline merges adjacent lanes only, and a 1 KiB store whose adjacent
+//    lanes sit on different rows is 64 separate requests (64 instead of 16 cycles of the CU's store path; tools/probe_store3.hip).
+//    Side inputs (residual rows, the second matrix of the row dots, the ReLU bit mask) are fetched in that transposed layout by
+//    inline-asm buffer loads the compiler does not count: half of them in phase 4 of the tile's last K-tile, half at the start
+//    of the epilogue, each waited for by a counted vmcnt.  The bias comes from a per-wave 1 KiB LDS copy of the tile's bias row,
+//    fetched by one more LDS-DMA of the same stream at the tile's start (an ordinary load would have to wait for every LDS-DMA
+//    issued before it) and added in f32 before the rounding, exactly as the other tile kernels do (acc * alpha + bias): results
+//    are bit-identical across kernels, i.e. across batch sizes.
+//  * Both wave groups run their epilogues side by side: waves 0-3 take one extra barrier at the epilogue's start (waves 4-7 finish
+//    their last MFMA cluster meanwhile), waves 4-7 one in front of the next tile, which staggers the groups again.  Staggered
+//    through the epilogue, each group sat at a barrier through the other's epilogue (tools/gemm_e_ktiles.py).
 #include "gemm_common.hpp"
 #include <type_traits>
 
