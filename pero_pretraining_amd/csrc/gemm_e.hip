@@ -148,6 +148,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p, int ks) {
   int T = blockIdx.x;
   long long tm0, tn0, nm0, nn0, kbeg = 0;
   bool has_next = false;
+  long long ws_slot = 0;   // split-K with a workspace: this work item's place among the partial tiles, (tile, slice) -> tile * slices + slice
   if (EPI == EP_SPLITK) {
     // work item = (tile, k-slice); the slices of one XCD's workgroups are the same few (operand panels fetched once per L2)
     const int xcd = T & 7, r = T >> 3;
@@ -161,6 +162,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p, int ks) {
     const int steps = (int)(p.K / E_BK), nsl = ks < 0 ? -ks : ks, base = steps / nsl, rem = steps % nsl;
     nk = base + (z < rem ? 1 : 0);
     kbeg = (long long)(z * base + (z < rem ? z : rem)) * E_BK;
+    ws_slot = (long long)id * nsl + z;
   } else {
     if (T >= nt) return;
     tile_of(T, tm0, tn0);
@@ -430,6 +432,22 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p, int ks) {
         ((unsigned long long*)p.gate)[((size_t)blockIdx.x * 2 + wr) * 32 + lane] = ((unsigned long long*)(smem + E_RING + 8192))[wr * 32 + lane];
       if ((VAR & 128) && wc == 0 && lane < 32)
         ((unsigned long long*)p.gate)[((size_t)blockIdx.x * 2 + wr) * 32 + lane] = ((unsigned long long*)(smem + E_RING + 8192))[wr * 32 + lane];
+      if (p.resid) {
+        // partial tile -> workspace with plain 16-byte stores, accumulator by accumulator: every wave-instruction writes 1 KiB of
+        // contiguous bytes ([accumulator][wave][lane] float4; pero_splitk_reduce_k knows the layout).  The slices of a tile are summed
+        // by that kernel in slice order: deterministic, and 6 TB/s of stores + one pass over the partials instead of f32 atomics, which
+        // the chip executes at 1.3 TB/s of added bytes (MI355X_MICROARCH.md): 64 MB per launch were ~49 us of every weight gradient.
+        f4v* const W = (f4v*)p.resid + ws_slot * (E_BM * E_BN / 4) + wave * 64 + lane;
+#pragma unroll
+        for (int ha = 0; ha < 2; ha++)
+#pragma unroll
+          for (int hb = 0; hb < 2; hb++)
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+              for (int j = 0; j < 2; j++) W[(((ha * 2 + hb) * 4 + i) * 2 + j) * 512] = acc[ha][hb][i][j];
+        return;
+      }
       float* const C = (float*)p.C;
 #pragma unroll
       for (int ha = 0; ha < 2; ha++) {
@@ -656,6 +674,43 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p, int ks) {
 #undef E_STAMP
 }
 
+// C[tile] += alpha * sum over the slices (in slice order) of the partial tiles the split-K work items left in the workspace.
+// One thread per float4 position of a tile: consecutive threads read consecutive 16 bytes of every partial tile.
+__global__ __launch_bounds__(256) void pero_splitk_reduce_k(const f4v* ws, float* C, long long ldc, int ntn, int nsl, float alpha) {
+  const int tile = blockIdx.x >> 6;                                   // 64 blocks of 256 threads per 256 x 256 tile
+  const int pos = ((blockIdx.x & 63) << 8) + threadIdx.x;             // (accumulator * 8 + wave) * 64 + lane
+  const f4v* src = ws + (long long)tile * nsl * (E_BM * E_BN / 4) + pos;
+  f4v sum = src[0];
+  for (int z = 1; z < nsl; z++) sum += src[(long long)z * (E_BM * E_BN / 4)];
+  const int lane = pos & 63, wave = (pos >> 6) & 7, idx = pos >> 9;
+  const int ha = idx >> 4, hb = (idx >> 3) & 1, i = (idx >> 1) & 3, j = idx & 1;
+  const long long row = (long long)(tile / ntn) * E_BM + 128 * (wave >> 2) + 64 * ha + 16 * i + (lane & 15);
+  const long long col = (long long)(tile % ntn) * E_BN + 64 * (wave & 3) + 32 * hb + 16 * j + 4 * (lane >> 4);
+  f4v* dst = (f4v*)(C + row * ldc + col);
+  *dst = *dst + sum * alpha;
+}
+// One workspace of 256 partial tiles (64 MiB) per stream that launches split-K products (at most four streams; a fifth, a launch
+// during stream capture before its workspace exists, or a failed allocation fall back to the atomic epilogue).
+static void* splitk_workspace(hipStream_t st, long long items) {
+  constexpr long long kItems = 256;
+  static struct { hipStream_t st; void* ptr; int dev; } slots[4];
+  static int nslots = 0;
+  if (items > kItems) return nullptr;
+  int dev = 0;
+  hipGetDevice(&dev);
+  for (int i = 0; i < nslots; i++)
+    if (slots[i].st == st && slots[i].dev == dev) return slots[i].ptr;
+  if (nslots == 4) return nullptr;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return nullptr; }
+  void* ptr = nullptr;
+  if (hipMalloc(&ptr, (size_t)kItems * E_BM * E_BN * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  slots[nslots].st = st; slots[nslots].ptr = ptr; slots[nslots].dev = dev;
+  nslots++;
+  return ptr;
+}
+int g_gemm_splitk_ws = 1;   // pero_set_option("splitk_workspace", 0): atomic epilogue
+
 // Qualifies: one problem (batch 1), no split-K, bf16 stored output, alpha == 1, M % 256 == N % 256 == K % 64 == 0, K >= 128.
 int g_gemm_e_var = 0;
 bool pero_launch_gemm_e256(const GemmP& p0, long long batch, int k_split, bool ta, bool tb, bool out_f32, hipStream_t st, int var) {
@@ -686,6 +741,13 @@ bool pero_launch_gemm_e256(const GemmP& p0, long long batch, int k_split, bool t
     GemmP p = p0;
     p.kchunk = 0;
     dim3 grid((unsigned)(tiles * ks)), block(512);
+    const int nsl = ks;
+    p.resid = (g_gemm_splitk_ws && !(var & (64 | 128)) && nsl > 1 && p0.ldc % 4 == 0 && (((size_t)p0.C) & 15) == 0) ? splitk_workspace(st, tiles * ks) : nullptr;
+    auto reduce = [&]() {
+      if (p.resid)
+        hipLaunchKernelGGL(pero_splitk_reduce_k, dim3((unsigned)(tiles * 64)), dim3(256), 0, st, (const f4v*)p.resid, (float*)p.C, (long long)p.ldc,
+                           (int)(p.N / E_BN), nsl, p.alpha);
+    };
     if (!xcd_ok) ks = -ks;
 #define LAUNCH_ES(TA_, TB_)                                                                                                \
   do {                                                                                                                     \
@@ -710,6 +772,7 @@ bool pero_launch_gemm_e256(const GemmP& p0, long long batch, int k_split, bool t
     }
     if (!ta && !tb) LAUNCH_ES(false, false); else if (!ta && tb) LAUNCH_ES(false, true); else if (ta && tb) LAUNCH_ES(true, true); else LAUNCH_ES(true, false);
 #undef LAUNCH_ES
+    reduce();
     return true;
   }
   if (k_split > 1 || out_f32 || (p0.flags & PERO_GEMM_ACCUM)) return false;

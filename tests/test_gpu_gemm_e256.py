@@ -118,3 +118,30 @@ def test_split_k_weight_gradient_mode(e256, N, K, rows):
     c = torch.ones(N, K, device="cuda")
     ops.gemm(dy, x, out=c, trans_a=True, trans_b=True, atomic=True, k_split=0, alpha=0.5)
     assert float((c.double() - (1.0 + 0.5 * ref)).abs().max()) <= 1e-5 * float(ref.abs().max()) * max(1, rows // 8192)
+
+
+def test_split_k_partial_tiles_are_summed_in_slice_order(e256):
+    """The split-K products leave their partial tiles in a workspace and a second kernel adds them in slice order: two runs give the
+    same bits (f32 atomics do not), the result is added to what C held, and it agrees with the atomic epilogue (option
+    "splitk_workspace" 0) to rounding."""
+    from pero_pretraining_amd._lib import call
+    ops = e256
+    torch.manual_seed(3)
+    rows, N, K = 65536, 768, 512
+    dy = (torch.randn(rows, N, device="cuda") * 0.5).bfloat16()
+    x = (torch.randn(rows, K, device="cuda") * 0.5).bfloat16()
+    runs = []
+    for _ in range(3):
+        c = torch.full((N, K), 0.25, device="cuda")
+        ops.gemm(dy, x, out=c, trans_a=True, trans_b=True, atomic=True, k_split=0)
+        runs.append(c)
+    assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2])
+    call("pero_set_option", b"splitk_workspace", 0)
+    try:
+        ca = torch.full((N, K), 0.25, device="cuda")
+        ops.gemm(dy, x, out=ca, trans_a=True, trans_b=True, atomic=True, k_split=0)
+    finally:
+        call("pero_set_option", b"splitk_workspace", 1)
+    ref = 0.25 + dy[:, :64].float().t() @ x.float()
+    assert float((runs[0][:64] - ref).abs().max()) < 2e-3 * float(ref.abs().max())
+    assert float((runs[0] - ca).abs().max()) < 1e-3 * float(ca.abs().max())

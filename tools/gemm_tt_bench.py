@@ -20,7 +20,9 @@ for (N, K, tag) in [(1536, 512, "qkv"), (512, 512, "out"), (2048, 512, "ffn1"), 
     res, outs = {}, {}
     for rep in range(2):
         for p in pols:
-            _lib.lib().pero_set_option(b"gemm_policy", p)
+            # p >= 100: automatic policy with the split-K workspace switched off (atomic epilogue)
+            _lib.lib().pero_set_option(b"gemm_policy", p % 100)
+            _lib.lib().pero_set_option(b"splitk_workspace", 0 if p >= 100 else 1)
             dw = torch.zeros(N, K, device="cuda")
             ops.gemm(dy, x, out=dw, trans_a=True, trans_b=True, atomic=True, k_split=0)
             outs[p] = dw.clone()
