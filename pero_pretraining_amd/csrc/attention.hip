@@ -327,6 +327,9 @@ __device__ __forceinline__ void attn_store_tile(const f16v (&acc)[4], unsigned c
     }
   __syncthreads();
   const int ch = tid & 15;
+  float cs[8];  // column sums of this thread's 8 columns (chunk ch) over its 8 rows, taken from the values on their way out
+#pragma unroll
+  for (int e = 0; e < 8; e++) cs[e] = 0.f;
 #pragma unroll 2
   for (int i = 0; i < 8; i++) {
     const int row = (tid >> 4) + 16 * i;
@@ -334,30 +337,35 @@ __device__ __forceinline__ void attn_store_tile(const f16v (&acc)[4], unsigned c
     uint4 v = *(const uint4*)(stg + row * 256 + ((ch ^ (x >> 1)) << 4));
     if (x & 1) { const unsigned t0 = v.x, t1 = v.y; v.x = v.z; v.y = v.w; v.z = t0; v.w = t1; }
     *(uint4*)(out_base + (long long)row * ld + ch * 8) = v;
+    if (colsum) {
+      const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int k = 0; k < 4; k++) { cs[2 * k] += __uint_as_float(w[k] << 16); cs[2 * k + 1] += __uint_as_float(w[k] & 0xffff0000u); }
+    }
   }
-  if (colsum) {  // thread: columns 2*c2, 2*c2 + 1 over rows quarter*32 .. +31; the four quarters meet in LDS
-    const int c2 = tid & 63, quarter = tid >> 6;
-    float s0 = 0.f, s1 = 0.f;
-#pragma unroll 4
-    for (int rr = 0; rr < 32; rr++) {
-      const int row = quarter * 32 + rr;
-      const unsigned w = *(const unsigned*)(stg + row * 256 + (((c2 >> 1) ^ (row & 31)) << 3) + (c2 & 1) * 4);
-      s0 += __uint_as_float(w << 16);
-      s1 += __uint_as_float(w & 0xffff0000u);
+  if (colsum) {
+    // the 16 threads with this chunk: lanes l, l ^ 16, l ^ 32, l ^ 48 of each wave (two exchanges per value), then the four waves
+    // through LDS; one partial row per workgroup and gradient, summed by attn_bias_reduce_k (atomics into the 128 addresses of a
+    // head from its 512 workgroups ran ~50 us longer per kernel than this)
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      cs[e] += __shfl_xor(cs[e], 16, 64);
+      cs[e] += __shfl_xor(cs[e], 32, 64);
     }
     __syncthreads();  // every thread is done reading the staged tile
     float* red = (float*)stg;
-    red[quarter * 128 + 2 * c2] = s0;
-    red[quarter * 128 + 2 * c2 + 1] = s1;
+    if ((tid & 63) < 16) {
+#pragma unroll
+      for (int e = 0; e < 8; e++) red[wave * 128 + ch * 8 + e] = cs[e];
+    }
     __syncthreads();
-    // one partial row per workgroup and gradient, summed by attn_bias_reduce_k: atomics into the 128 addresses of a head
-    // from its 512 workgroups ran ~50 us longer per kernel than this
     if (tid < 128) colsum[tid] = (red[tid] + red[128 + tid]) + (red[256 + tid] + red[384 + tid]);
   }
 }
 
 // dbias[which * d + head * 128 + c] += sum over the workgroups (line, block) of partial[which][(lh, blk)][c], lh = line * nh + head.
-// Grid (heads, 3, 16 slices of the workgroup list): 16 atomics per address.
+// Grid (heads, 3, slices of the workgroup list): one atomic per address and slice.  64 slices at >= 4096 workgroups per head (16 slices
+// were 192 blocks of two waves for 12.6 MB of partial rows: 37 us, latency-bound).
 __global__ __launch_bounds__(128) void attn_bias_reduce_k(const float* partial, float* dbias, int nlines, int nh, int nblk) {
   const int c = threadIdx.x, head = blockIdx.x, which = blockIdx.y;
   const long long nwg = (long long)nlines * nh * nblk;
@@ -614,7 +622,7 @@ extern "C" int pero_attention_bwd(const void* qkv, const void* out, const void* 
                      (bf16raw*)dqkv, dbias ? work : nullptr, (int)S, (int)num_heads, c, scale);
   }
   if (dbias)
-    hipLaunchKernelGGL(attn_bias_reduce_k, dim3((unsigned)num_heads, 3, 16), dim3(128), 0, st, work, dbias, (int)N, (int)num_heads, (int)(S / 128));
+    hipLaunchKernelGGL(attn_bias_reduce_k, dim3((unsigned)num_heads, 3, (N * (S / 128) >= 1024) ? 64 : 16), dim3(128), 0, st, work, dbias, (int)N, (int)num_heads, (int)(S / 128));
   PERO_CHECK_LAUNCH("pero_attention_bwd");
   return PERO_OK;
 }
