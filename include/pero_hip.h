@@ -60,7 +60,7 @@ int pero_abi_version(void);
  * kernel; 0 = never), "gemm_e_splitk_min" (4), "gemm_e_var" (diagnostic builds of that kernel), "splitk_items" (512), "splitk_xcd" (1),
  * "splitk_nearest" (0), "attn_bwd_pair" (1: the attention backward with D handed in runs as one launch, csrc/attention.hip), "splitk_workspace" (1: the split-K
  * products of the eight-phase kernel leave partial tiles in a 64 MiB workspace per stream, summed in slice order by a second kernel - deterministic;
- * 0: f32 atomics).  Process-wide; not meant to be changed while products are in flight. */
+ * 0: f32 atomics), "splitk_table" (1: unaligned slice counts hand their work items out XCD by XCD).  Process-wide; not meant to be changed while products are in flight. */
 int pero_set_option(const char* name, int value);
 
 /* ---- front end ------------------------------------------------------------------------------

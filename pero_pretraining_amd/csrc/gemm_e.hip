@@ -35,6 +35,7 @@
 //    through the epilogue, each group sat at a barrier through the other's epilogue (tools/gemm_e_ktiles.py).
 #include "gemm_common.hpp"
 #include <type_traits>
+#include <vector>
 
 #define E_BM 256
 #define E_BN 256
@@ -153,7 +154,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p, int ks) {
     // work item = (tile, k-slice); the slices of one XCD's workgroups are the same few (operand panels fetched once per L2)
     const int xcd = T & 7, r = T >> 3;
     int id, z;
-    if (ks < 0) { id = T / (-ks); z = T % (-ks); }  // any slice count: plain order
+    if (ks < 0 && p.bias) { const unsigned e = ((const unsigned*)p.bias)[T]; id = (int)(e >> 8); z = (int)(e & 255u); }  // table (launcher)
+    else if (ks < 0) { id = T / (-ks); z = T % (-ks); }  // any slice count: plain order
     else if (ks >= 8) { const int per = ks >> 3; z = xcd * per + (r % per); id = r / per; }
     else { z = xcd % ks; id = r * (8 / ks) + xcd / ks; }
     tm0 = (long long)(id / ntn) * E_BM; tn0 = (long long)(id % ntn) * E_BN;
@@ -710,6 +712,44 @@ static void* splitk_workspace(hipStream_t st, long long items) {
   return ptr;
 }
 int g_gemm_splitk_ws = 1;   // pero_set_option("splitk_workspace", 0): atomic epilogue
+// Work-item table for slice counts that are no multiple of 8 (e.g. 12 tiles x 21 slices): workgroup T runs on XCD T & 7; slice z belongs
+// to XCD z % 8, and an XCD takes the (tile, slice) items of its own slices first, slice by slice, so that the tiles which stream the same
+// operand panels meet in one L2; what an XCD has too many of (an XCD with three slices has 36 items for 31-32 workgroups) goes to the
+// XCDs with room.  In plain order (item = T) every XCD fetched every panel: K-tiles of 4.2 k cycles against 3.6 k with aligned slices.
+// Tables live in device memory, one per (tiles, slices) pair, made at the first launch of that shape (not during stream capture).
+static const unsigned* splitk_item_table(hipStream_t st, int tiles, int nsl) {
+  static struct { int tiles, nsl, dev; unsigned* ptr; } cache[16];
+  static int ncache = 0;
+  int dev = 0;
+  hipGetDevice(&dev);
+  for (int i = 0; i < ncache; i++)
+    if (cache[i].tiles == tiles && cache[i].nsl == nsl && cache[i].dev == dev) return cache[i].ptr;
+  const int n = tiles * nsl;
+  if (ncache == 16 || n > 4096 || nsl > 255) return nullptr;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return nullptr; }
+  std::vector<unsigned> tab((size_t)n, 0xffffffffu), pool;
+  std::vector<std::vector<unsigned>> own(8);
+  for (int z = 0; z < nsl; z++)
+    for (int id = 0; id < tiles; id++) own[z & 7].push_back(((unsigned)id << 8) | (unsigned)z);
+  for (int x = 0; x < 8; x++) {
+    const int cap = (n - x + 7) / 8;   // workgroups T = x, x + 8, ... < n
+    while ((int)own[x].size() > cap) { pool.push_back(own[x].back()); own[x].pop_back(); }
+  }
+  for (int x = 0; x < 8; x++) {
+    const int cap = (n - x + 7) / 8;
+    while ((int)own[x].size() < cap && !pool.empty()) { own[x].push_back(pool.back()); pool.pop_back(); }
+    for (int k = 0; k < (int)own[x].size(); k++) tab[(size_t)k * 8 + x] = own[x][k];
+  }
+  for (unsigned e : tab) if (e == 0xffffffffu) return nullptr;   // (cannot happen: the capacities add up to n)
+  unsigned* ptr = nullptr;
+  if (hipMalloc((void**)&ptr, (size_t)n * sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  if (hipMemcpy(ptr, tab.data(), (size_t)n * sizeof(unsigned), hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); hipFree(ptr); return nullptr; }
+  cache[ncache].tiles = tiles; cache[ncache].nsl = nsl; cache[ncache].dev = dev; cache[ncache].ptr = ptr;
+  ncache++;
+  return ptr;
+}
+int g_gemm_splitk_table = 1;   // pero_set_option("splitk_table", 0): plain item order for unaligned slice counts
 
 // Qualifies: one problem (batch 1), no split-K, bf16 stored output, alpha == 1, M % 256 == N % 256 == K % 64 == 0, K >= 128.
 int g_gemm_e_var = 0;
@@ -748,7 +788,10 @@ bool pero_launch_gemm_e256(const GemmP& p0, long long batch, int k_split, bool t
         hipLaunchKernelGGL(pero_splitk_reduce_k, dim3((unsigned)(tiles * 64)), dim3(256), 0, st, (const f4v*)p.resid, (float*)p.C, (long long)p.ldc,
                            (int)(p.N / E_BN), nsl, p.alpha);
     };
-    if (!xcd_ok) ks = -ks;
+    if (!xcd_ok) {
+      ks = -ks;
+      p.bias = (g_gemm_splitk_table && !(var & (64 | 128))) ? (const float*)splitk_item_table(st, (int)tiles, nsl) : nullptr;
+    }
 #define LAUNCH_ES(TA_, TB_)                                                                                                \
   do {                                                                                                                     \
     static bool attr_set = false;                                                                                          \

@@ -22,7 +22,8 @@ for (N, K, tag) in [(1536, 512, "qkv"), (512, 512, "out"), (2048, 512, "ffn1"), 
         for p in pols:
             # p >= 100: automatic policy with the split-K workspace switched off (atomic epilogue)
             _lib.lib().pero_set_option(b"gemm_policy", p % 100)
-            _lib.lib().pero_set_option(b"splitk_workspace", 0 if p >= 100 else 1)
+            _lib.lib().pero_set_option(b"splitk_workspace", 0 if 100 <= p < 200 else 1)
+            _lib.lib().pero_set_option(b"splitk_table", 0 if p >= 200 else 1)   # p >= 200: plain item order for unaligned slice counts
             dw = torch.zeros(N, K, device="cuda")
             ops.gemm(dy, x, out=dw, trans_a=True, trans_b=True, atomic=True, k_split=0)
             outs[p] = dw.clone()
