@@ -16,6 +16,11 @@
 #include "common.hpp"
 
 #define AT_HALF_BYTES 16384   // 64 rows x 256 B
+#ifndef AT_NO_PRIO
+#define AT_PRIO(n_) __builtin_amdgcn_s_setprio(n_)
+#else
+#define AT_PRIO(n_)
+#endif
 #define AT_SUB_BYTES 8192     // 32 rows x 256 B
 #define AT_DKV2_LDS (4 * AT_SUB_BYTES + 128 * 128 * 2 + 512)  // Q / dO stages x 2, V tile, row statistics x 2
 #define AT_TILE_BYTES (128 * 128 * 2)  // 32 KiB: 128 keys x 128 head-dim bf16
@@ -110,6 +115,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_k(const bf16raw* qkv, bf16raw
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // K(u) landed
     f16v s[4];
+    AT_PRIO(1);   // this wave's MFMA cluster goes ahead of the other wave's softmax instructions on the same SIMD
 #pragma unroll
     for (int t = 0; t < 4; t++) {
       s[t] = (f16v){0};
@@ -117,6 +123,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_k(const bf16raw* qkv, bf16raw
       for (int ks = 0; ks < 8; ks++)
         s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(attn_k_frag(kimg, t * 32 + r, ks, h5), qf[ks], s[t], 0, 0, 0);
     }
+    AT_PRIO(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // own part of V(u)
     __syncthreads();  // every wave is done with the K image; V(u) landed
     if (u + 1 < units) {
@@ -154,6 +161,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_k(const bf16raw* qkv, bf16raw
     }
 
     // ---- O^T += V^T P^T
+    AT_PRIO(1);
 #pragma unroll
     for (int t = 0; t < 4; t++) {
 #pragma unroll
@@ -164,6 +172,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_k(const bf16raw* qkv, bf16raw
           o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(attn_vT_frag(vimg, t * 32 + sub * 16, dt, lane), pf, o[dt], 0, 0, 0);
       }
     }
+    AT_PRIO(0);
     if (kt == nkt - 1) {
       // ---- head finished: O[q][d] = o[dt][reg] / l, staged through the (now free) V image so that HBM sees whole
       // 256-byte rows in 16-byte lanes: the direct form (16 scattered 8-byte stores per lane) cost 23 % of the kernel
@@ -449,16 +458,19 @@ __device__ __forceinline__ void attn_bwd_dq_body(unsigned char* smem, int lh, in
 #pragma unroll
     for (int t = 0; t < 2; t++) {  // 32-key sub-tile
       f16v s = {0}, dp = {0};
+      AT_PRIO(1);
 #pragma unroll
       for (int ks = 0; ks < 8; ks++) {
         s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_row_frag(kimg, t * 32 + r, ks, h5), qf[ks], s, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_row_frag(vimg, t * 32 + r, ks, h5), gf[ks], dp, 0, 0, 0);
       }
+      AT_PRIO(0);
 #pragma unroll
       for (int e = 0; e < 16; e++) {
         const float p = __builtin_amdgcn_exp2f(fmaf(s[e], c, -lq));
         s[e] = p * (dp[e] - dsum) * scale;  // dS^T
       }
+      AT_PRIO(1);
 #pragma unroll
       for (int sub = 0; sub < 2; sub++) {
         const bf8v dsf = pack8(s, sub);
@@ -466,6 +478,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(unsigned char* smem, int lh, in
         for (int dt = 0; dt < 4; dt++)
           dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_tr_frag(kimg, t * 32 + sub * 16, dt, lane), dsf, dq[dt], 0, 0, 0);
       }
+      AT_PRIO(0);
     }
   }
   // dbias: partial-sum workspace [3][workgroups][128] (q, k, v); this kernel fills plane 0
@@ -534,11 +547,13 @@ __device__ __forceinline__ void attn_bwd_dkv2_body(unsigned char* smem, int lh, 
     }
     // rows q = (e&3) + 8(e>>2) + 4*h5 of the 32-query stage on the registers, key on the lane
     f16v s = {0}, dp = {0};
+    AT_PRIO(1);
 #pragma unroll
     for (int ks = 0; ks < 8; ks++) {
       s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_row_frag(qimg, r, ks, h5), kf[ks], s, 0, 0, 0);
       dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_row_frag(gimg, r, ks, h5), img_row_frag(vimg, wave * 32 + r, ks, h5), dp, 0, 0, 0);
     }
+    AT_PRIO(0);
 #pragma unroll
     for (int g4 = 0; g4 < 4; g4++) {
       const f4v l4 = *(const f4v*)(lds_l + 8 * g4 + 4 * h5);
@@ -550,6 +565,7 @@ __device__ __forceinline__ void attn_bwd_dkv2_body(unsigned char* smem, int lh, 
         dp[4 * g4 + e] = p * (dp[4 * g4 + e] - d4[e]) * scale;     // dS
       }
     }
+    AT_PRIO(1);
 #pragma unroll
     for (int sub = 0; sub < 2; sub++) {
       const bf8v pf = pack8(s, sub), dsf = pack8(dp, sub);
@@ -559,6 +575,7 @@ __device__ __forceinline__ void attn_bwd_dkv2_body(unsigned char* smem, int lh, 
         dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_tr_frag(qimg, sub * 16, dt, lane), dsf, dk[dt], 0, 0, 0);  // dK^T += Q^T dS
       }
     }
+    AT_PRIO(0);
     if (sq + 1 < nsub && tid < 64) lds_ld[((sq + 1) & 1) * 64 + tid] = nstat;  // visible after the next barrier
   }
   bf16raw* tile_o = dqkv + ((long long)line * S + kb * 128) * ld + d + head * 128;  // dK tile; dV tile = + d columns
