@@ -526,7 +526,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p, int ks) {
 #pragma unroll
             for (int hb = 0; hb < 2; hb++) {
               const int i = ib + ii;
-              const f4v x = acc[ha][hb][i][0] + bx[hb][0], y = acc[ha][hb][i][1] + bx[hb][1];  // (alpha = 1: the other kernels' acc * alpha + bias, bit for bit)
+              // (alpha = 1: the other kernels' acc * alpha + bias, bit for bit; the modes that never take a bias skip the add of zero)
+              const f4v x = EPI <= EP_RELU_BITS ? acc[ha][hb][i][0] + bx[hb][0] : acc[ha][hb][i][0];
+              const f4v y = EPI <= EP_RELU_BITS ? acc[ha][hb][i][1] + bx[hb][1] : acc[ha][hb][i][1];
               if (EPI == EP_RESID) {
                 // f32 columns first (one rounding): even lane groups keep x and take the odd neighbour's x, odd ones y
                 float v[8];
