@@ -685,7 +685,15 @@ __global__ __launch_bounds__(256) void pero_splitk_reduce_k(const f4v* ws, float
   const int pos = ((blockIdx.x & 63) << 8) + threadIdx.x;             // (accumulator * 8 + wave) * 64 + lane
   const f4v* src = ws + (long long)tile * nsl * (E_BM * E_BN / 4) + pos;
   f4v sum = src[0];
-  for (int z = 1; z < nsl; z++) sum += src[(long long)z * (E_BM * E_BN / 4)];
+  int z = 1;
+  for (; z + 8 <= nsl; z += 8) {   // eight partial tiles requested together, added in slice order
+    f4v v[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) v[k] = src[(long long)(z + k) * (E_BM * E_BN / 4)];
+#pragma unroll
+    for (int k = 0; k < 8; k++) sum += v[k];
+  }
+  for (; z < nsl; z++) sum += src[(long long)z * (E_BM * E_BN / 4)];
   const int lane = pos & 63, wave = (pos >> 6) & 7, idx = pos >> 9;
   const int ha = idx >> 4, hb = (idx >> 3) & 1, i = (idx >> 1) & 3, j = idx & 1;
   const long long row = (long long)(tile / ntn) * E_BM + 128 * (wave >> 2) + 64 * ha + 16 * i + (lane & 15);
