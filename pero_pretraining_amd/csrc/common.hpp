@@ -39,6 +39,29 @@ __device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, pk_b2));
 }
 
+// eight consecutive elements as one (bf16) or two (f32) 16-byte accesses, f32 values in registers
+template <typename T> __device__ __forceinline__ void load8(const T* p, float (&v)[8]);
+template <> __device__ __forceinline__ void load8<float>(const float* p, float (&v)[8]) {
+  const f4v a = *(const f4v*)p, b = *(const f4v*)(p + 4);
+  v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+}
+template <> __device__ __forceinline__ void load8<bf16raw>(const bf16raw* p, float (&v)[8]) {
+  const uint4 r = *(const uint4*)p;
+  const unsigned w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+  for (int e = 0; e < 4; e++) { v[2 * e] = __uint_as_float(w[e] << 16); v[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u); }
+}
+template <typename T> __device__ __forceinline__ void store8(T* p, const float (&v)[8]);
+template <> __device__ __forceinline__ void store8<float>(float* p, const float (&v)[8]) {
+  *(f4v*)p = (f4v){v[0], v[1], v[2], v[3]};
+  *(f4v*)(p + 4) = (f4v){v[4], v[5], v[6], v[7]};
+}
+template <> __device__ __forceinline__ void store8<bf16raw>(bf16raw* p, const float (&v)[8]) {
+  uint4 o;
+  o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]); o.z = pack2bf(v[4], v[5]); o.w = pack2bf(v[6], v[7]);
+  *(uint4*)p = o;
+}
+
 template <typename T> struct Elem;
 template <> struct Elem<float> {
   static __device__ __forceinline__ float ld(const float* p) { return *p; }

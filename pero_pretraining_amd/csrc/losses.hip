@@ -2,12 +2,13 @@
 // The dense contractions (VICReg covariance SYRK, its backward, the per-line NT-Xent similarity matrices and
 // their backward products) run on pero_gemm; everything here is HBM-bound row/column work in f32 statistics.
 #include "common.hpp"
+#include <initializer_list>
 
 // --------------------------------------------------------------------------------------------
 // squared-difference sum of gathered rows (VICReg invariance, losses.py:14-16):
 //   partial[row] = sum_c (x[ix[row]][c] - y[iy[row]][c])^2      (one wave per row, deterministic)
 // --------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, bool V8>
 __global__ __launch_bounds__(256) void sqdiff_rows_k(const T* x, const int64_t* ix, const T* y, const int64_t* iy, float* partial,
                                                      long long n, int d) {
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -15,7 +16,16 @@ __global__ __launch_bounds__(256) void sqdiff_rows_k(const T* x, const int64_t* 
   const T* a = x + ix[row] * d;
   const T* b = y + iy[row] * d;
   float s = 0.f;
-  for (int c = threadIdx.x & 63; c < d; c += 64) { const float t = Elem<T>::ld(a + c) - Elem<T>::ld(b + c); s += t * t; }
+  if (V8) {  // 16-byte accesses: d % 8 == 0, 16-byte aligned rows (the scalar loop moved 2 bytes per lane and instruction)
+    for (int c = (threadIdx.x & 63) * 8; c < d; c += 512) {
+      float va[8], vb[8];
+      load8<T>(a + c, va); load8<T>(b + c, vb);
+#pragma unroll
+      for (int e = 0; e < 8; e++) { const float t = va[e] - vb[e]; s += t * t; }
+    }
+  } else {
+    for (int c = threadIdx.x & 63; c < d; c += 64) { const float t = Elem<T>::ld(a + c) - Elem<T>::ld(b + c); s += t * t; }
+  }
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) partial[row] = s;
 }
@@ -30,13 +40,23 @@ __global__ __launch_bounds__(256) void sum_scale_k(const float* partial, float* 
   if (threadIdx.x == 0) out[0] = ((sm[0] + sm[1]) + (sm[2] + sm[3])) * scale;
 }
 // dx[ix[row]] += g*coef*(x-y), dy[iy[row]] -= g*coef*(x-y)   (rows of ix / iy are unique)
-template <typename T>
+template <typename T, bool V8>
 __global__ __launch_bounds__(256) void sqdiff_rows_bwd_k(const T* x, const int64_t* ix, const T* y, const int64_t* iy, T* dx, T* dy,
                                                          const float* g, float coef, long long n, int d) {
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= n) return;
   const float c0 = coef * (g ? g[0] : 1.f);
   const long long ra = ix[row], rb = iy[row];
+  if (V8) {
+    for (int c = (threadIdx.x & 63) * 8; c < d; c += 512) {
+      float vx[8], vy[8], gx[8], gy[8];
+      load8<T>(x + ra * d + c, vx); load8<T>(y + rb * d + c, vy); load8<T>(dx + ra * d + c, gx); load8<T>(dy + rb * d + c, gy);
+#pragma unroll
+      for (int e = 0; e < 8; e++) { const float t = c0 * (vx[e] - vy[e]); gx[e] += t; gy[e] -= t; }
+      store8<T>(dx + ra * d + c, gx); store8<T>(dy + rb * d + c, gy);
+    }
+    return;
+  }
   for (int c = threadIdx.x & 63; c < d; c += 64) {
     const float t = c0 * (Elem<T>::ld(x + ra * d + c) - Elem<T>::ld(y + rb * d + c));
     Elem<T>::st(dx + ra * d + c, Elem<T>::ld(dx + ra * d + c) + t);
@@ -48,7 +68,7 @@ __global__ __launch_bounds__(256) void sqdiff_rows_bwd_k(const T* x, const int64
 // VICReg statistics (losses.py:37-47).  z: (m_pad, d) gathered rows, rows >= m are zero padding.
 // center: zc = z - mean (padding rows stay 0), sumsq[c] += sum_rows zc^2.   colsum (= m * mean) is an input.
 // --------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, bool V8>
 __global__ __launch_bounds__(256) void center_cols_k(const T* z, const float* colsum, T* zc, float* sumsq, long long m, long long m_pad, int d) {
   __shared__ float red[8][256 + 8];
   const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
@@ -61,13 +81,23 @@ __global__ __launch_bounds__(256) void center_cols_k(const T* z, const float* co
     const long long r0 = (long long)blockIdx.y * 128;
     const long long r1 = r0 + 128 < m_pad ? r0 + 128 : m_pad;
     for (long long r = r0 + rl; r < r1; r += 8) {
+      float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (r < m) {
+        if (V8) load8<T>(z + r * d + col, v);
+        else {
 #pragma unroll
-      for (int e = 0; e < 8; e++) {
-        float v = 0.f;
-        if (r < m) { v = Elem<T>::ld(z + r * d + col + e) - mu[e]; }
-        Elem<T>::st(zc + r * d + col + e, v);
-        acc[e] += v * v;
+          for (int e = 0; e < 8; e++) v[e] = Elem<T>::ld(z + r * d + col + e);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; e++) v[e] -= mu[e];
       }
+      if (V8) store8<T>(zc + r * d + col, v);
+      else {
+#pragma unroll
+        for (int e = 0; e < 8; e++) Elem<T>::st(zc + r * d + col + e, v[e]);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; e++) acc[e] += v[e] * v[e];
     }
   }
 #pragma unroll
@@ -119,12 +149,22 @@ __global__ __launch_bounds__(256) void vicreg_cov_k(const float* cov, const floa
   if (threadIdx.x == 0) rowpart[i] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
 }
 // dst[index[i]] += g * src[i]
-template <typename T>
+template <typename T, bool V8>
 __global__ __launch_bounds__(256) void scatter_add_scaled_k(const T* src, const int64_t* index, T* dst, const float* g, long long n, int d) {
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= n) return;
   const float gs = g ? g[0] : 1.f;
   T* o = dst + index[row] * d;
+  if (V8) {
+    for (int c = (threadIdx.x & 63) * 8; c < d; c += 512) {
+      float a[8], b[8];
+      load8<T>(o + c, a); load8<T>(src + row * d + c, b);
+#pragma unroll
+      for (int e = 0; e < 8; e++) a[e] += gs * b[e];
+      store8<T>(o + c, a);
+    }
+    return;
+  }
   for (int c = threadIdx.x & 63; c < d; c += 64) Elem<T>::st(o + c, Elem<T>::ld(o + c) + gs * Elem<T>::ld(src + row * d + c));
 }
 
@@ -132,26 +172,64 @@ __global__ __launch_bounds__(256) void scatter_add_scaled_k(const T* src, const 
 // NT-Xent (losses.py:56-83): L2 row normalisation and the column-normalised softmax-CE of per-line S x S
 // similarity matrices.
 // --------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, bool V8>
 __global__ __launch_bounds__(256) void rownorm_fwd_k(const T* x, T* xn, float* inv, long long rows, int d) {
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   float s = 0.f;
-  for (int c = threadIdx.x & 63; c < d; c += 64) { const float v = Elem<T>::ld(x + row * d + c); s += v * v; }
+  if (V8) {
+    for (int c = (threadIdx.x & 63) * 8; c < d; c += 512) {
+      float v[8];
+      load8<T>(x + row * d + c, v);
+#pragma unroll
+      for (int e = 0; e < 8; e++) s += v[e] * v[e];
+    }
+  } else {
+    for (int c = threadIdx.x & 63; c < d; c += 64) { const float v = Elem<T>::ld(x + row * d + c); s += v * v; }
+  }
   s = wave_sum(s);
   const float r = 1.0f / fmaxf(sqrtf(s), 1e-12f);  // F.normalize eps
   if ((threadIdx.x & 63) == 0) inv[row] = r;
+  if (V8) {
+    for (int c = (threadIdx.x & 63) * 8; c < d; c += 512) {
+      float v[8];
+      load8<T>(x + row * d + c, v);
+#pragma unroll
+      for (int e = 0; e < 8; e++) v[e] *= r;
+      store8<T>(xn + row * d + c, v);
+    }
+    return;
+  }
   for (int c = threadIdx.x & 63; c < d; c += 64) Elem<T>::st(xn + row * d + c, Elem<T>::ld(x + row * d + c) * r);
 }
 // dx = (dxn - xn * <xn, dxn>) * inv
-template <typename T>
+template <typename T, bool V8>
 __global__ __launch_bounds__(256) void rownorm_bwd_k(const T* xn, const T* dxn, const float* inv, const float* g, T* dx, long long rows, int d) {
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   float s = 0.f;
-  for (int c = threadIdx.x & 63; c < d; c += 64) s += Elem<T>::ld(xn + row * d + c) * Elem<T>::ld(dxn + row * d + c);
+  if (V8) {
+    for (int c = (threadIdx.x & 63) * 8; c < d; c += 512) {
+      float a[8], b[8];
+      load8<T>(xn + row * d + c, a); load8<T>(dxn + row * d + c, b);
+#pragma unroll
+      for (int e = 0; e < 8; e++) s += a[e] * b[e];
+    }
+  } else {
+    for (int c = threadIdx.x & 63; c < d; c += 64) s += Elem<T>::ld(xn + row * d + c) * Elem<T>::ld(dxn + row * d + c);
+  }
   s = wave_sum(s);
   const float r = inv[row] * (g ? g[0] : 1.f);
+  if (V8) {
+    for (int c = (threadIdx.x & 63) * 8; c < d; c += 512) {
+      float a[8], b[8];
+      load8<T>(xn + row * d + c, a); load8<T>(dxn + row * d + c, b);
+#pragma unroll
+      for (int e = 0; e < 8; e++) b[e] = (b[e] - a[e] * s) * r;
+      store8<T>(dx + row * d + c, b);
+    }
+    return;
+  }
   for (int c = threadIdx.x & 63; c < d; c += 64)
     Elem<T>::st(dx + row * d + c, (Elem<T>::ld(dxn + row * d + c) - Elem<T>::ld(xn + row * d + c) * s) * r);
 }
@@ -188,12 +266,22 @@ __global__ __launch_bounds__(256) void ntxent_cols_k(const float* sim, float* li
     else PERO_REQUIRE(false, "bad dtype");                                                        \
   } while (0)
 
+// 16-byte row accesses are possible when every row starts 16-byte aligned
+static inline bool v8_ok(int64_t d, int dtype, std::initializer_list<const void*> ptrs) {
+  const int esz = dtype == PERO_F32 ? 4 : 2;
+  if (d % 8 || (d * esz) % 16) return false;
+  for (const void* q : ptrs) if (!aligned16(q)) return false;
+  return true;
+}
+
 extern "C" int pero_sqdiff_rows(const void* x, const int64_t* ix, const void* y, const int64_t* iy, float* partial, float* out,
                                 int64_t n, int64_t d, float scale, int dtype, void* stream) {
   PERO_REQUIRE(x && y && ix && iy && partial && out && n > 0 && d > 0, "pero_sqdiff_rows: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((unsigned)((n + 3) / 4)), block(256);
-#define L_(T, ...) hipLaunchKernelGGL((sqdiff_rows_k<T>), grid, block, 0, st, (const T*)x, ix, (const T*)y, iy, partial, (long long)n, (int)d)
+  const bool v8 = v8_ok(d, dtype, {x, y});
+#define L_(T, ...) do { if (v8) hipLaunchKernelGGL((sqdiff_rows_k<T, true>), grid, block, 0, st, (const T*)x, ix, (const T*)y, iy, partial, (long long)n, (int)d); \
+                        else hipLaunchKernelGGL((sqdiff_rows_k<T, false>), grid, block, 0, st, (const T*)x, ix, (const T*)y, iy, partial, (long long)n, (int)d); } while (0)
   DISPATCH_T(dtype, L_, 0);
 #undef L_
   hipLaunchKernelGGL(sum_scale_k, dim3(1), dim3(256), 0, st, partial, out, (long long)n, scale);
@@ -204,7 +292,9 @@ extern "C" int pero_sqdiff_rows_bwd(const void* x, const int64_t* ix, const void
                                     const float* g, float coef, int64_t n, int64_t d, int dtype, void* stream) {
   PERO_REQUIRE(x && y && ix && iy && dx && dy && n > 0 && d > 0, "pero_sqdiff_rows_bwd: bad arguments");
   dim3 grid((unsigned)((n + 3) / 4)), block(256);
-#define L_(T, ...) hipLaunchKernelGGL((sqdiff_rows_bwd_k<T>), grid, block, 0, (hipStream_t)stream, (const T*)x, ix, (const T*)y, iy, (T*)dx, (T*)dy, g, coef, (long long)n, (int)d)
+  const bool v8 = v8_ok(d, dtype, {x, y, dx, dy});
+#define L_(T, ...) do { if (v8) hipLaunchKernelGGL((sqdiff_rows_bwd_k<T, true>), grid, block, 0, (hipStream_t)stream, (const T*)x, ix, (const T*)y, iy, (T*)dx, (T*)dy, g, coef, (long long)n, (int)d); \
+                        else hipLaunchKernelGGL((sqdiff_rows_bwd_k<T, false>), grid, block, 0, (hipStream_t)stream, (const T*)x, ix, (const T*)y, iy, (T*)dx, (T*)dy, g, coef, (long long)n, (int)d); } while (0)
   DISPATCH_T(dtype, L_, 0);
 #undef L_
   PERO_CHECK_LAUNCH("pero_sqdiff_rows_bwd");
@@ -220,7 +310,9 @@ extern "C" int pero_center_cols(const void* z, const float* colsum, void* zc, fl
                                 int dtype, void* stream) {
   PERO_REQUIRE(z && colsum && zc && sumsq && m > 1 && m_pad >= m && d > 0 && d % 8 == 0, "pero_center_cols: bad arguments (d %% 8 == 0)");
   dim3 grid((unsigned)((d + 255) / 256), (unsigned)((m_pad + 127) / 128)), block(256);
-#define L_(T, ...) hipLaunchKernelGGL((center_cols_k<T>), grid, block, 0, (hipStream_t)stream, (const T*)z, colsum, (T*)zc, sumsq, (long long)m, (long long)m_pad, (int)d)
+  const bool v8 = v8_ok(d, dtype, {z, zc});
+#define L_(T, ...) do { if (v8) hipLaunchKernelGGL((center_cols_k<T, true>), grid, block, 0, (hipStream_t)stream, (const T*)z, colsum, (T*)zc, sumsq, (long long)m, (long long)m_pad, (int)d); \
+                        else hipLaunchKernelGGL((center_cols_k<T, false>), grid, block, 0, (hipStream_t)stream, (const T*)z, colsum, (T*)zc, sumsq, (long long)m, (long long)m_pad, (int)d); } while (0)
   DISPATCH_T(dtype, L_, 0);
 #undef L_
   PERO_CHECK_LAUNCH("pero_center_cols");
@@ -248,7 +340,9 @@ extern "C" int pero_scatter_add_rows_scaled(const void* src, const int64_t* inde
                                             int dtype, void* stream) {
   PERO_REQUIRE(src && index && dst && n > 0 && d > 0, "pero_scatter_add_rows_scaled: bad arguments");
   dim3 grid((unsigned)((n + 3) / 4)), block(256);
-#define L_(T, ...) hipLaunchKernelGGL((scatter_add_scaled_k<T>), grid, block, 0, (hipStream_t)stream, (const T*)src, index, (T*)dst, g, (long long)n, (int)d)
+  const bool v8 = v8_ok(d, dtype, {src, dst});
+#define L_(T, ...) do { if (v8) hipLaunchKernelGGL((scatter_add_scaled_k<T, true>), grid, block, 0, (hipStream_t)stream, (const T*)src, index, (T*)dst, g, (long long)n, (int)d); \
+                        else hipLaunchKernelGGL((scatter_add_scaled_k<T, false>), grid, block, 0, (hipStream_t)stream, (const T*)src, index, (T*)dst, g, (long long)n, (int)d); } while (0)
   DISPATCH_T(dtype, L_, 0);
 #undef L_
   PERO_CHECK_LAUNCH("pero_scatter_add_rows_scaled");
@@ -257,7 +351,9 @@ extern "C" int pero_scatter_add_rows_scaled(const void* src, const int64_t* inde
 extern "C" int pero_rownorm_fwd(const void* x, void* xn, float* inv, int64_t rows, int64_t d, int dtype, void* stream) {
   PERO_REQUIRE(x && xn && inv && rows > 0 && d > 0, "pero_rownorm_fwd: bad arguments");
   dim3 grid((unsigned)((rows + 3) / 4)), block(256);
-#define L_(T, ...) hipLaunchKernelGGL((rownorm_fwd_k<T>), grid, block, 0, (hipStream_t)stream, (const T*)x, (T*)xn, inv, (long long)rows, (int)d)
+  const bool v8 = v8_ok(d, dtype, {x, xn});
+#define L_(T, ...) do { if (v8) hipLaunchKernelGGL((rownorm_fwd_k<T, true>), grid, block, 0, (hipStream_t)stream, (const T*)x, (T*)xn, inv, (long long)rows, (int)d); \
+                        else hipLaunchKernelGGL((rownorm_fwd_k<T, false>), grid, block, 0, (hipStream_t)stream, (const T*)x, (T*)xn, inv, (long long)rows, (int)d); } while (0)
   DISPATCH_T(dtype, L_, 0);
 #undef L_
   PERO_CHECK_LAUNCH("pero_rownorm_fwd");
@@ -267,7 +363,9 @@ extern "C" int pero_rownorm_bwd(const void* xn, const void* dxn, const float* in
                                 int dtype, void* stream) {
   PERO_REQUIRE(xn && dxn && inv && dx && rows > 0 && d > 0, "pero_rownorm_bwd: bad arguments");
   dim3 grid((unsigned)((rows + 3) / 4)), block(256);
-#define L_(T, ...) hipLaunchKernelGGL((rownorm_bwd_k<T>), grid, block, 0, (hipStream_t)stream, (const T*)xn, (const T*)dxn, inv, g, (T*)dx, (long long)rows, (int)d)
+  const bool v8 = v8_ok(d, dtype, {xn, dxn, dx});
+#define L_(T, ...) do { if (v8) hipLaunchKernelGGL((rownorm_bwd_k<T, true>), grid, block, 0, (hipStream_t)stream, (const T*)xn, (const T*)dxn, inv, g, (T*)dx, (long long)rows, (int)d); \
+                        else hipLaunchKernelGGL((rownorm_bwd_k<T, false>), grid, block, 0, (hipStream_t)stream, (const T*)xn, (const T*)dxn, inv, g, (T*)dx, (long long)rows, (int)d); } while (0)
   DISPATCH_T(dtype, L_, 0);
 #undef L_
   PERO_CHECK_LAUNCH("pero_rownorm_bwd");

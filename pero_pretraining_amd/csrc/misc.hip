@@ -281,11 +281,22 @@ extern "C" int pero_adam_step(float* p, const float* g, float* m, float* v, void
 // row gather / scatter-add (boolean-mask row selections of the losses; d % 8 == 0 fast path not needed:
 // one wave per row, scalar elements, rows are >= 96 bytes)
 // ---------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, bool V16>
 __global__ __launch_bounds__(256) void gather_rows_k(const T* src, const int64_t* index, T* dst, long long n_idx, long long n_out, int d) {
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= n_out) return;
   const int lane = threadIdx.x & 63;
+  if (V16) {  // rows of whole 16-byte pieces (d * sizeof(T) % 16 == 0, aligned bases): one uint4 per lane and step
+    const int n16 = d * (int)sizeof(T) / 16;
+    uint4* o = (uint4*)(dst + row * d);
+    if (row < n_idx) {
+      const uint4* s = (const uint4*)(src + index[row] * d);
+      for (int c = lane; c < n16; c += 64) o[c] = s[c];
+    } else {
+      for (int c = lane; c < n16; c += 64) o[c] = make_uint4(0, 0, 0, 0);
+    }
+    return;
+  }
   if (row < n_idx) {
     const T* s = src + index[row] * d;
     for (int c = lane; c < d; c += 64) dst[row * d + c] = s[c];
@@ -293,30 +304,46 @@ __global__ __launch_bounds__(256) void gather_rows_k(const T* src, const int64_t
     for (int c = lane; c < d; c += 64) Elem<T>::st(dst + row * d + c, 0.f);
   }
 }
-template <typename T>
+template <typename T, bool V16>
 __global__ __launch_bounds__(256) void scatter_add_rows_k(const T* src, const int64_t* index, T* dst, long long n_idx, int d) {
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= n_idx) return;
   const int lane = threadIdx.x & 63;
   T* o = dst + index[row] * d;
+  if (V16) {
+    for (int c = lane * 8; c < d; c += 512) {
+      float a[8], b[8];
+      load8<T>(o + c, a); load8<T>(src + row * d + c, b);
+#pragma unroll
+      for (int e = 0; e < 8; e++) a[e] += b[e];
+      store8<T>(o + c, a);
+    }
+    return;
+  }
   for (int c = lane; c < d; c += 64) Elem<T>::st(o + c, Elem<T>::ld(o + c) + Elem<T>::ld(src + row * d + c));
 }
 extern "C" int pero_gather_rows(const void* src, const int64_t* index, void* dst, int64_t n_idx, int64_t n_rows_out, int64_t d,
                                 int dtype, void* stream) {
   PERO_REQUIRE(src && dst && (index || n_idx == 0) && n_rows_out >= n_idx && n_rows_out > 0 && d > 0, "pero_gather_rows: bad arguments");
   dim3 grid((unsigned)((n_rows_out + 3) / 4)), block(256);
-  if (dtype == PERO_F32) hipLaunchKernelGGL((gather_rows_k<float>), grid, block, 0, (hipStream_t)stream, (const float*)src, index, (float*)dst, (long long)n_idx, (long long)n_rows_out, (int)d);
-  else if (dtype == PERO_BF16) hipLaunchKernelGGL((gather_rows_k<bf16raw>), grid, block, 0, (hipStream_t)stream, (const bf16raw*)src, index, (bf16raw*)dst, (long long)n_idx, (long long)n_rows_out, (int)d);
+  const bool v16 = d % 8 == 0 && aligned16(src) && aligned16(dst);
+#define G_(T, V) hipLaunchKernelGGL((gather_rows_k<T, V>), grid, block, 0, (hipStream_t)stream, (const T*)src, index, (T*)dst, (long long)n_idx, (long long)n_rows_out, (int)d)
+  if (dtype == PERO_F32) { if (v16) G_(float, true); else G_(float, false); }
+  else if (dtype == PERO_BF16) { if (v16) G_(bf16raw, true); else G_(bf16raw, false); }
   else PERO_REQUIRE(false, "pero_gather_rows: bad dtype");
+#undef G_
   PERO_CHECK_LAUNCH("pero_gather_rows");
   return PERO_OK;
 }
 extern "C" int pero_scatter_add_rows(const void* src, const int64_t* index, void* dst, int64_t n_idx, int64_t d, int dtype, void* stream) {
   PERO_REQUIRE(src && dst && index && n_idx > 0 && d > 0, "pero_scatter_add_rows: bad arguments");
   dim3 grid((unsigned)((n_idx + 3) / 4)), block(256);
-  if (dtype == PERO_F32) hipLaunchKernelGGL((scatter_add_rows_k<float>), grid, block, 0, (hipStream_t)stream, (const float*)src, index, (float*)dst, (long long)n_idx, (int)d);
-  else if (dtype == PERO_BF16) hipLaunchKernelGGL((scatter_add_rows_k<bf16raw>), grid, block, 0, (hipStream_t)stream, (const bf16raw*)src, index, (bf16raw*)dst, (long long)n_idx, (int)d);
+  const bool v16 = d % 8 == 0 && aligned16(src) && aligned16(dst);
+#define S_(T, V) hipLaunchKernelGGL((scatter_add_rows_k<T, V>), grid, block, 0, (hipStream_t)stream, (const T*)src, index, (T*)dst, (long long)n_idx, (int)d)
+  if (dtype == PERO_F32) { if (v16) S_(float, true); else S_(float, false); }
+  else if (dtype == PERO_BF16) { if (v16) S_(bf16raw, true); else S_(bf16raw, false); }
   else PERO_REQUIRE(false, "pero_scatter_add_rows: bad dtype");
+#undef S_
   PERO_CHECK_LAUNCH("pero_scatter_add_rows");
   return PERO_OK;
 }

@@ -3,28 +3,6 @@
 // statistics), 16-byte global accesses, f32 statistics whatever the storage dtype.
 #include "common.hpp"
 
-template <typename T> __device__ __forceinline__ void load8(const T* p, float (&v)[8]);
-template <> __device__ __forceinline__ void load8<float>(const float* p, float (&v)[8]) {
-  const f4v a = *(const f4v*)p, b = *(const f4v*)(p + 4);
-  v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
-}
-template <> __device__ __forceinline__ void load8<bf16raw>(const bf16raw* p, float (&v)[8]) {
-  const uint4 r = *(const uint4*)p;
-  const unsigned w[4] = {r.x, r.y, r.z, r.w};
-#pragma unroll
-  for (int e = 0; e < 4; e++) { v[2 * e] = __uint_as_float(w[e] << 16); v[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u); }
-}
-template <typename T> __device__ __forceinline__ void store8(T* p, const float (&v)[8]);
-template <> __device__ __forceinline__ void store8<float>(float* p, const float (&v)[8]) {
-  *(f4v*)p = (f4v){v[0], v[1], v[2], v[3]};
-  *(f4v*)(p + 4) = (f4v){v[4], v[5], v[6], v[7]};
-}
-template <> __device__ __forceinline__ void store8<bf16raw>(bf16raw* p, const float (&v)[8]) {
-  uint4 o;
-  o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]); o.z = pack2bf(v[4], v[5]); o.w = pack2bf(v[6], v[7]);
-  *(uint4*)p = o;
-}
-
 // ---------------------------------------------------------------------------------------------
 // LayerNorm forward.  d % 8 == 0, d <= 512 * NCH.  4 waves per block, one row per wave.
 // ---------------------------------------------------------------------------------------------
