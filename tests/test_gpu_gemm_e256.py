@@ -145,3 +145,32 @@ def test_split_k_partial_tiles_are_summed_in_slice_order(e256):
     ref = 0.25 + dy[:, :64].float().t() @ x.float()
     assert float((runs[0][:64] - ref).abs().max()) < 2e-3 * float(ref.abs().max())
     assert float((runs[0] - ca).abs().max()) < 1e-3 * float(ca.abs().max())
+
+
+def test_strided_views_of_every_operand(e256):
+    """Column slices of wider tensors as A, B, C, the residual and the row-dot matrix (leading dimensions larger than the row
+    length): the epilogue's transposed lane layout addresses rows by their pitch - same bytes as the other tile kernel, and
+    nothing outside the slice is touched."""
+    ops = e256
+    torch.manual_seed(5)
+    M, N, K = 1024, 512, 256
+    xa = (torch.randn(M, K + 64, device="cuda") * 0.5).bfloat16()
+    wa = (torch.randn(N, K + 128, device="cuda") * 0.5).bfloat16()
+    ra = torch.randn(M, N + 256, device="cuda").bfloat16()
+    x, w, res = xa[:, 64:], wa[:, :K], ra[:, 128:128 + N]
+    bias = torch.randn(N, device="cuda")
+    outs = {}
+    for pol in (20, 7):
+        _setpol(pol)
+        ca = torch.full((M, N + 512), 7.0, device="cuda").bfloat16()
+        ops.gemm(x, w, out=ca[:, 256:256 + N], bias=bias, residual=res)
+        dots = torch.zeros((M, N // 128), device="cuda")
+        yd = ops.gemm(x, w, rowdot=(res, dots))
+        outs[pol] = (ca, yd, dots)
+    _setpol(20)
+    assert torch.equal(outs[20][0], outs[7][0]) and torch.equal(outs[20][1], outs[7][1])
+    assert float((outs[20][2] - outs[7][2]).abs().max()) <= 1e-3 * float(outs[7][2].abs().max())
+    ca = outs[20][0]
+    assert torch.all(ca[:, :256] == 7.0) and torch.all(ca[:, 256 + N:] == 7.0)
+    ref = x.float() @ w.float().t() + bias + res.float()
+    assert float((ca[:, 256:256 + N].float() - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
