@@ -721,6 +721,9 @@ static void* splitk_workspace(hipStream_t st, long long items) {
   nslots++;
   return ptr;
 }
+__global__ __launch_bounds__(256) void pero_zero16_k(f4v* p, long long n16) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long long)gridDim.x * 256) p[i] = (f4v){0.f, 0.f, 0.f, 0.f};
+}
 int g_gemm_splitk_ws = 1;   // pero_set_option("splitk_workspace", 0): atomic epilogue
 // Work-item table for slice counts that are no multiple of 8 (e.g. 12 tiles x 21 slices): workgroup T runs on XCD T & 7; slice z belongs
 // to XCD z % 8, and an XCD takes the (tile, slice) items of its own slices first, slice by slice, so that the tiles which stream the same
@@ -856,7 +859,13 @@ bool pero_launch_gemm_e256(const GemmP& p0, long long batch, int k_split, bool t
   unsigned G = (unsigned)(nt < num_cus ? ((nt + 7) / 8) * 8 : num_cus);
   if (wg_cap && (unsigned)wg_cap < G) G = (unsigned)wg_cap;
   dim3 grid(G), block(512);
-  if (epi == EP_ROWDOT) hipMemsetAsync((void*)p.bias, 0, (size_t)p.M * (size_t)(p.N >> 7) * sizeof(float), st);  // the two waves of a 128-column block add into it
+  if (epi == EP_ROWDOT) {  // the two waves of a 128-column block add into it: cleared first (hipMemsetAsync's fill kernel took 27 us for these 4 MB)
+    const long long n = p.M * (p.N >> 7);
+    if (n % 4 == 0 && aligned16(p.bias))
+      hipLaunchKernelGGL(pero_zero16_k, dim3((unsigned)((n / 4 + 255) / 256 < 2048 ? (n / 4 + 255) / 256 : 2048)), dim3(256), 0, st, (f4v*)p.bias, n / 4);
+    else
+      hipMemsetAsync((void*)p.bias, 0, (size_t)n * sizeof(float), st);
+  }
 #define LAUNCH_E(TA_, TB_, EP_, VAR_)                                                                                            \
   do {                                                                                                                     \
     static bool attr_set = false;                                                                                          \
