@@ -2,26 +2,32 @@
 """Throughput of the masked-pretraining step (BASELINE.json configs[1]): 12-layer d=512 ViT over
 40x2048 synthetic uint8 lines, V=4096, bf16 MFMA, one process per GPU.
 
+  python bench.py                                   (1 GPU, SURVEY 8d protocol: 20 warm-up, 5 repeats of 100 steps, median)
   python bench.py --gpus 1 --steps 20 --warmup 5
+  python bench.py --gpus N ...                      (no RANK in the environment: starts the N ranks itself, see self_launch)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-      bench.py --gpus N --steps K --warmup W
+      bench.py --gpus N --steps K --warmup W        (the driver's form; one rank per GPU over RCCL)
 
-A step = zero_grad -> front end (u8 -> patches, mask tile) -> 12 encoder layers -> head -> masked CE ->
-backward of all of it -> [gradient all-reduce] -> fused Adam.  Prints ONE JSON line (rank 0).
+A step = BatchOperator.prepare_batch (host mask draw, labels / mask upload; the uint8 line images are ALREADY RESIDENT in HBM) ->
+zero_grad -> front end (u8 -> /255 -> mask tile -> patches) -> 12 encoder layers -> head -> masked CE -> backward of all of it ->
+[gradient all-reduce] -> fused Adam: the reference's Trainer.train_step (masked_pretraining/trainer.py:53-68).  ONE JSON line (rank 0).
 
-  value               whole-job lines/s with the batch resident in HBM when the timed region starts: the MEDIAN of three
-                      repeats of exactly --steps steps, each bracketed by barrier + synchronize (max over ranks)
-  with_prepare_batch  the same step INCLUDING BatchOperator.prepare_batch: host mask draw + the uint8 batch from pinned host
-                      memory over PCIe on a copy stream, double-buffered against the previous step (never `value`)
+  value               whole-job lines/s of that step: the MEDIAN over `--repeats` repeats of exactly --steps steps, each bracketed by
+                      barrier + synchronize (max over ranks)
+  resident_step       the same without prepare_batch in the timed region (labels and mask resident too: train_step_prepared only)
+  with_h2d            prepare_batch INCLUDING the uint8 batch from pinned host memory over PCIe (copy stream, double-buffered) - never `value`
   roofline            the bf16 tile GEMM: algorithmic flops / HIP-event duration of every launch of two extra steps
-  legs                driver-visible numbers of the other single-GPU configs: config 3 (codebook argmin, its own roofline vs the
-                      f32 MFMA peak), configs 4 / 5 (VICReg / NT-Xent joint steps, per-GPU share), medians of three repeats
+  legs                configs[2] (codebook argmin), configs[3] (VICReg step; under N > 1 with data-parallel gradients, per-rank and exact
+                      global statistics), configs[4] (NT-Xent step, 512 lines per GPU; under N > 1 with cross-rank negatives)
   cpu_baseline        the CPU oracle (oracle/pero_oracle.py, a "port") on the host cores, a bounded sample of the same workload
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
 import statistics
+import subprocess
 import sys
 import time
 
@@ -34,23 +40,83 @@ sys.path.insert(0, ROOT)
 
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense, /opt/skills/guides/MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
 F32_MFMA_PEAK_TFLOPS = 157.3    # same table, "Peak FP32 (matrix)"
-REPEATS = 3
 
 CFG = dict(num_blocks=12, model_dim=512, num_heads=4, feedforward_dim=2048, vocab=4096, width=2048, height=40,
            patch=8, channels=3)
 
 
-def flops_per_line(c=CFG):
-    """forward F = patch + L*(qkv + attn + out + ffn) + head; step = 3F."""
+def flops_per_line(c=CFG, masked_frac=None):
+    """forward F = patch + L*(qkv + attn + out + ffn) + head; step = 3F.  With `masked_frac` the EXECUTED count:
+    the head's two backward products run on the masked rows only (the other rows of dlogits are exact zeros)."""
     S, d, L, ff, V = c["width"] // c["patch"], c["model_dim"], c["num_blocks"], c["feedforward_dim"], c["vocab"]
     kp = c["channels"] * c["height"] * c["patch"]
-    F = 2 * S * kp * d + L * (2 * S * d * 3 * d + 4 * S * S * d + 2 * S * d * d + 4 * S * d * ff) + 2 * S * d * V
-    return 3 * F
+    head = 2 * S * d * V
+    F = 2 * S * kp * d + L * (2 * S * d * 3 * d + 4 * S * S * d + 2 * S * d * d + 4 * S * d * ff) + head
+    if masked_frac is None:
+        return 3 * F
+    return 3 * F - 2 * head * (1.0 - masked_frac)
 
 
+def csrc_hash():
+    """sha256 over the kernel sources: a committed PMC profile is only quoted while it describes THIS code."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "pero_pretraining_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".hpp")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(batch):
+    """HBM bytes per GEMM launch from the committed rocprofv3 --pmc summary (profiles/, separate FETCH_SIZE / WRITE_SIZE passes of
+    this command: tools/pmc_traffic.sh).  bench.py cannot run the profiler on itself, so the number is quoted ONLY when the summary
+    was collected for this batch size from exactly these kernel sources (`csrc_sha256`); otherwise null."""
+    here = csrc_hash()
+    for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
+        if not (name.endswith("pmc_gemm_traffic.json")):
+            continue
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                d = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if int(d.get("lines_per_gpu", -1)) == int(batch) and d.get("csrc_sha256") == here:
+            return d.get("hbm_bytes_per_launch"), name
+    return None, None
+
+
+# ------------------------------------------------------------------------------------------------ launching
+def self_launch(args, argv):
+    """`python bench.py --gpus N` without RANK in the environment: start the N ranks as a CHILD process
+    (python -m torch.distributed.run ... bench.py ...) BEFORE anything here touches the GPU, relay its one JSON line and exit with its
+    code.  The parent never initialises HIP (a process that has must not exec or be replaced on this pool)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    child_argv = [a for a in argv if a != "--spawn"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + child_argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["PERO_BENCH_SELF_LAUNCHED"] = "1"
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)
+    line = None
+    for ln in proc.stdout.decode(errors="replace").splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line)
+    sys.exit(proc.returncode if proc.returncode or line is not None else 1)
+
+
+# ------------------------------------------------------------------------------------------------ model / data
 def build(device, bf16):
     from pero_pretraining_amd.common.lr_scheduler import WarmupSchleduler
     from pero_pretraining_amd.masked_pretraining import model as M
+    from pero_pretraining_amd.masked_pretraining.batch_operator import BatchOperator
     from pero_pretraining_amd.masked_pretraining.trainer import Trainer
     from pero_pretraining_amd.optim import FusedAdam
     torch.manual_seed(0)
@@ -60,19 +126,23 @@ def build(device, bf16):
     model = M.MaskedTransformerEncoder(bb, hd).to(device).train()
     opt = FusedAdam(model.parameters(), lr=2e-4)
     sched = WarmupSchleduler(opt, 2e-4, 10000, 1)
-    trainer = Trainer(None, model, None, opt, sched, bfloat16=bf16)
+    trainer = Trainer(BatchOperator(device, 0.15), model, None, opt, sched, bfloat16=bf16)
     return model, opt, sched, trainer
 
 
 def synthetic(rank, B, device, nbatches=2):
+    """SURVEY 8d synthetic inputs.  Per batch: the uint8 images on the device (resident in HBM), the labels on the host AND on the
+    device, a pre-drawn mask on the device (for the resident_step leg only; `value` draws its masks in prepare_batch)."""
     rng = np.random.default_rng(1234 + rank)
     W, S = CFG["width"], CFG["width"] // CFG["patch"]
     out = []
     for _ in range(nbatches):
         images = torch.from_numpy(rng.integers(0, 256, (B, CFG["height"], W, CFG["channels"]), dtype=np.uint8)).to(device)
-        labels = torch.from_numpy(rng.integers(0, CFG["vocab"], (B, S)).astype(np.int64)).to(device)
-        mask = torch.from_numpy((rng.random((B, S)) < 0.15).astype(np.int64)).to(device)
-        out.append((images, labels, mask))
+        labels_h = rng.integers(0, CFG["vocab"], (B, S)).astype(np.int64)
+        mask_h = (rng.random((B, S)) < 0.15).astype(np.int64)
+        mask = torch.from_numpy(mask_h).to(device)
+        mask._pero_host = mask_h   # what BatchOperator / DevicePrefetcher attach: the host original of an uploaded mask
+        out.append({"images": images, "labels": labels_h, "labels_dev": torch.from_numpy(labels_h).to(device), "mask_dev": mask})
     return out
 
 
@@ -109,31 +179,20 @@ def cpu_baseline(budget_s=20.0, B=8):
             "sample": f"{n} steps of B={B} lines (40x2048, 12-layer d=512, f32) through oracle/pero_oracle.py MaskedStepOracle"}
 
 
-def pmc_traffic(batch):
-    """HBM bytes per GEMM launch from the committed rocprofv3 --pmc summary of this command (profiles/), if it was
-    collected for this batch size; None otherwise (bench.py cannot run the profiler on itself)."""
-    for name in ("r02_pmc_gemm_traffic.json", "r01_pmc_gemm_traffic.json"):
-        try:
-            with open(os.path.join(ROOT, "profiles", name)) as f:
-                d = json.load(f)
-            if int(d.get("lines_per_gpu", -1)) == int(batch):
-                return d.get("hbm_bytes_per_launch")
-        except (OSError, ValueError):
-            pass
-    return None
-
-
 class Timer:
     """K steps bracketed by barrier + synchronize on both sides, max over ranks; median over repeats."""
 
     def __init__(self, device):
         self.device = device
+        self.cuda = device.type == "cuda"
 
     def fence(self):
-        torch.cuda.synchronize()
+        if self.cuda:
+            torch.cuda.synchronize()
         if dist.is_initialized():
             dist.barrier()
-        torch.cuda.synchronize()
+        if self.cuda:
+            torch.cuda.synchronize()
 
     def run(self, step, steps, first=0):
         self.fence()
@@ -149,7 +208,7 @@ class Timer:
             el = float(t[0])
         return el, out
 
-    def median(self, step, steps, repeats=REPEATS, first=0):
+    def median(self, step, steps, repeats, first=0):
         els, out = [], None
         for r in range(repeats):
             el, out = self.run(step, steps, first + r * steps)
@@ -157,6 +216,47 @@ class Timer:
         return statistics.median(els), els, out
 
 
+def timed_gemms(run_steps, nsteps):
+    """Every pero_gemm launch of `nsteps` steps bracketed by HIP events on the stream it is launched on (the weight gradients are
+    put on the main stream for this leg, so no two kernels share the chip while timed) -> {tag: [seconds, flops, launches]}."""
+    from pero_pretraining_amd import functional as F
+    from pero_pretraining_amd import ops
+    side_was = F.SIDE_STREAM_DW
+    F.SIDE_STREAM_DW = False
+    run_steps(1)
+    torch.cuda.synchronize()
+    ops.gemm_timeline = []
+    run_steps(nsteps)
+    torch.cuda.synchronize()
+    tl, ops.gemm_timeline = ops.gemm_timeline, None
+    F.SIDE_STREAM_DW = side_was
+    per = {}
+    for e0, e1, fl, tag in tl:
+        d = per.setdefault(tag, [0.0, 0.0, 0])
+        d[0] += e0.elapsed_time(e1) * 1e-3
+        d[1] += fl
+        d[2] += 1
+    return per
+
+
+def gemm_roofline(per, nsteps, step_seconds, traffic):
+    fast = {k: v for k, v in per.items() if k.startswith("gemm_bf16_tile")}
+    tsum = sum(v[0] for v in fast.values()) or 1e-30
+    fsum = sum(v[1] for v in fast.values())
+    nl = sum(v[2] for v in fast.values()) or 1
+    ach = fsum / tsum / 1e12
+    return {"bound": "mfma",
+            "kernel": "bf16 MFMA tile GEMM gemm_bf16_e256 (eight-phase persistent 256x256x64: forward, input gradients with fused "
+                      "epilogues, split-K weight gradients)",
+            "achieved": round(ach, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4),
+            "traffic": traffic, "launches_per_step": nl // nsteps, "avg_launch_us": round(tsum / nl * 1e6, 2),
+            "gflop_per_launch": round(fsum / nl / 1e9, 3),
+            "gemm_time_share_of_step": round((tsum / nsteps) / step_seconds, 3),
+            "by_layout": {k: {"tflops": round(v[1] / v[0] / 1e12, 1), "ms_per_step": round(v[0] / nsteps * 1e3, 3),
+                              "launches_per_step": v[2] // nsteps} for k, v in sorted(per.items())}}
+
+
+# ------------------------------------------------------------------------------------------------ legs
 def leg_config3(timer, device):
     """BASELINE.json configs[2]: codebook argmin of the VQ tokenizer, K = 8192 codes x D = 512, the rows of 128 lines."""
     from pero_pretraining_amd import ops
@@ -181,22 +281,30 @@ def leg_config3(timer, device):
                          "traffic": None}}
 
 
-def leg_joint(timer, device, kind, pairs, steps):
+def leg_joint(timer, device, kind, pairs, steps, repeats, world, rank, variant=None):
     """BASELINE.json configs[3] / [4], one GPU's share: joint-embedding step (two views through the 12-layer backbone as one 2N
-    batch + linear head 4096 + VICReg / NT-Xent + backward + fused Adam) on `pairs` line pairs of 40x2048."""
+    batch + linear head 4096 + VICReg / NT-Xent + backward + [gradient all-reduce] + fused Adam) on `pairs` line pairs of 40x2048 per
+    GPU.  variant: VICReg "global" = exact global statistics over all ranks; NT-Xent "cross" = cross-rank negatives (all-gather)."""
     from pero_pretraining_amd.common.lr_scheduler import WarmupSchleduler
     from pero_pretraining_amd.joint_embedding_pretraining import model as J
     from pero_pretraining_amd.joint_embedding_pretraining.batch_operator import BatchOperator
     from pero_pretraining_amd.joint_embedding_pretraining.losses import NTXentLoss, VICRegLoss
     from pero_pretraining_amd.joint_embedding_pretraining.trainer import Trainer
     from pero_pretraining_amd.optim import FusedAdam
+    from pero_pretraining_amd.parallel import DataParallel
     torch.manual_seed(0)
     bb = J.init_backbone({"num_blocks": 12, "model_dim": 512, "num_heads": 4, "feedforward_dim": 2048})
     hd = J.init_head({"type": "linear", "in_features": 512, "out_features": 4096})
-    model = J.JointEmbeddingTransformerEncoder(bb, hd, VICRegLoss() if kind == "vicreg" else NTXentLoss()).to(device).train()
+    if kind == "vicreg":
+        loss = VICRegLoss(global_statistics=(variant == "global"))
+    else:
+        loss = NTXentLoss(cross_rank_negatives=(variant == "cross"))
+    model = J.JointEmbeddingTransformerEncoder(bb, hd, loss).to(device).train()
     opt = FusedAdam(model.parameters(), lr=1e-4)
     tr = Trainer(BatchOperator(device), model, None, opt, WarmupSchleduler(opt, 1e-4, 100, 1), bfloat16=True)
-    rng = np.random.default_rng(5)
+    if dist.is_initialized():
+        tr.data_parallel = DataParallel(model, opt)
+    rng = np.random.default_rng(5 + rank)
     S = 256
     ones = np.ones((pairs, S), np.uint8)
     sm1 = ones.copy()
@@ -210,35 +318,54 @@ def leg_joint(timer, device, kind, pairs, steps):
     prepared = tr.batch_operator.prepare_batch(batch)   # resident in HBM (masks keep their host copies: no device sync)
     for i in range(2):
         tr.train_step_prepared(*prepared)
-    med, els, loss = timer.median(lambda i: tr.train_step_prepared(*prepared), steps)
+    med, els, loss_v = timer.median(lambda i: tr.train_step_prepared(*prepared), steps, repeats)
+    per = timed_gemms(lambda n: [tr.train_step_prepared(*prepared) for _ in range(n)], 1)
+    roof = gemm_roofline(per, 1, med / steps, None)
     del model, opt, tr
-    return {"workload": f"{'VICReg' if kind == 'vicreg' else 'NT-Xent'} joint-embedding step, 12-layer d=512 ViT + linear head 4096, {pairs} line pairs "
-                        f"of 40x2048 per GPU, bf16 (BASELINE.json configs[{3 if kind == 'vicreg' else 4}], one GPU's share)",
-            "ms_per_step": round(med / steps * 1e3, 3), "line_pairs_per_s": round(pairs * steps / med, 1),
-            "repeats_ms_per_step": [round(e / steps * 1e3, 3) for e in els], "loss": round(float(loss), 5)}
+    name = "VICReg" if kind == "vicreg" else "NT-Xent"
+    return {"workload": f"{name} joint-embedding step, 12-layer d=512 ViT + linear head 4096, {pairs} line pairs of 40x2048 per GPU, bf16 "
+                        f"(BASELINE.json configs[{3 if kind == 'vicreg' else 4}]" + (", one GPU's share)" if world == 1 else f", {world} GPUs)"),
+            "variant": {"vicreg": {None: "per-rank statistics", "global": "exact global statistics (two extra all-reduces: D + 1 floats, D x D f32)"},
+                        "ntxent": {None: "per-line negatives (the reference's loss)", "cross": "cross-rank negatives: pooled embeddings all-gathered"}}[kind][variant],
+            "ms_per_step": round(med / steps * 1e3, 3), "line_pairs_per_s": round(world * pairs * steps / med, 1),
+            "repeats_ms_per_step": [round(e / steps * 1e3, 3) for e in els], "loss": round(float(loss_v), 5),
+            "distributed": {"world_size": world, "backend": dist.get_backend() if dist.is_initialized() else None},
+            "roofline": roof}
 
 
+# ------------------------------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)     # warm-up 20 steps, time >= 100 steps, median of 5 repeats
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--repeats", type=int, default=5)
     ap.add_argument("--batch", type=int, default=int(os.environ.get("PERO_BENCH_BATCH", 1024)), help="lines per GPU")
     ap.add_argument("--no-side-stream", action="store_true", help="weight gradients on the main stream (clean per-kernel profiles)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the config 3 / 4 / 5 legs")
+    ap.add_argument("--legs-only", action="store_true", help="only the config 3 / 4 / 5 legs (profiling)")
     ap.add_argument("--dp-no-overlap", action="store_true", help="data parallel: reduce all gradients after the backward pass (A/B of the bucket hooks)")
     ap.add_argument("--dp-layers-per-bucket", type=int, default=2)
-    ap.add_argument("--no-options", action="store_true", help="skip the extra legs (masked head, prepare_batch pipeline)")
+    ap.add_argument("--no-options", action="store_true", help="skip the extra legs (resident step, PCIe-inclusive step, masked head)")
+    ap.add_argument("--head-backward", default="masked", choices=["masked", "dense"],
+                    help="head backward on the masked rows only (default: the other rows of dlogits are exact zeros) or over all rows")
     ap.add_argument("--masked-head", action="store_true",
-                    help="OPTION, not the headline: head + loss on the masked positions only (model.head_rows = 'masked'); "
+                    help="OPTION, not the headline: head FORWARD + loss on the masked positions only (model.head_rows = 'masked'); "
                          "the default evaluates the head on every position like the reference")
+    ap.add_argument("--spawn", action="store_true", help="start the rank(s) through torch.distributed.run even for --gpus 1 (RCCL with one rank)")
+    ap.add_argument("--plumbing-test", action="store_true", help=argparse.SUPPRESS)   # CPU / gloo rehearsal of launch + timing + relay (tests)
     args = ap.parse_args()
+
+    if "RANK" not in os.environ and (args.gpus > 1 or args.spawn):
+        self_launch(args, sys.argv[1:])     # never returns
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit(f"bench.py --gpus {args.gpus} but WORLD_SIZE={world}")
     # Under torch.distributed.run RCCL prints a version banner on the C-level stdout at communicator creation: everything but the ONE
     # JSON line goes to stderr (file descriptor 1 is pointed at stderr; the line is written to the saved descriptor at the end)
     real_stdout = None
@@ -246,169 +373,193 @@ def main():
         sys.stdout.flush()
         real_stdout = os.dup(1)
         os.dup2(2, 1)
+
+    def emit(out):
+        if rank != 0:
+            return
+        if real_stdout is None:
+            print(json.dumps(out))
+        else:
+            sys.stdout.flush()
+            os.write(real_stdout, (json.dumps(out) + "\n").encode())
+
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    if args.plumbing_test:
+        return plumbing_test(args, world, rank, emit)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     backend = None
-    if world > 1 or "RANK" in os.environ:  # launched by torch.distributed.run (also with one rank: same code path)
+    if "RANK" in os.environ:  # launched by torch.distributed.run (also with one rank: same code path)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", device_id=device)
         backend = dist.get_backend()
 
     from pero_pretraining_amd import functional as F
-    from pero_pretraining_amd import ops
     from pero_pretraining_amd.parallel import DataParallel
     if args.no_side_stream:
         F.SIDE_STREAM_DW = False
-    bf16 = args.dtype == "bf16"
-    model, opt, sched, trainer = build(device, bf16)
-    if args.masked_head:
-        model.head_rows = "masked"
-    if dist.is_initialized():
-        trainer.data_parallel = DataParallel(model, opt, overlap=not args.dp_no_overlap, layers_per_bucket=args.dp_layers_per_bucket)
-    batches = synthetic(rank, args.batch, device)
     timer = Timer(device)
+    bf16 = args.dtype == "bf16"
+    out = {"metric": "text-line images/sec (masked-ViT step)", "unit": "lines/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic"}
+    S = CFG["width"] // CFG["patch"]
 
-    # --masked-head: the positions are listed once per resident batch (in training the mask is drawn on the host, so the
-    # list costs no device sync there either)
-    row_lists = [torch.nonzero(b[2].reshape(-1) == 1).reshape(-1) for b in batches]
+    if not args.legs_only:
+        model, opt, sched, trainer = build(device, bf16)
+        model.head_backward = args.head_backward
+        if args.masked_head:
+            model.head_rows = "masked"
+        if dist.is_initialized():
+            trainer.data_parallel = DataParallel(model, opt, overlap=not args.dp_no_overlap, layers_per_bucket=args.dp_layers_per_bucket)
+        batches = synthetic(rank, args.batch, device)
+        np.random.seed(4321 + rank)   # prepare_batch draws its masks from numpy's global stream (the reference's call)
 
-    def step(i):
-        sched.update_learning_rate(i)
-        images, labels, mask = batches[i % len(batches)]
-        rows = row_lists[i % len(batches)] if model.head_rows == "masked" else None
-        return trainer.train_step_prepared(images, labels, mask, rows=rows)
-
-    # ---- headline: batch resident in HBM
-    for i in range(args.warmup):
-        step(i)
-    elapsed, repeats, loss = timer.median(step, args.steps, first=args.warmup)
-    final_loss = float(loss)
-    lines_per_s = world * args.batch * args.steps / elapsed
-    step_flops = flops_per_line()
-    head_rows = model.head_rows
-
-    # ---- the same step including BatchOperator.prepare_batch: host mask draw (numpy, the reference's call) + u8 batch over PCIe
-    # from pinned host memory on a copy stream, double-buffered against the previous step
-    with_prepare = None
-    if not args.no_options and not args.masked_head:
+        # the reference's train_step = prepare_batch + the step.  prepare_batch (numpy mask draw, labels and mask to the device) runs
+        # for every step inside the timed region, one batch ahead on a copy stream from pinned staging buffers
+        # (common/dataloader.DevicePrefetcher: a pageable upload would stall the launching thread); the uint8 images it is
+        # handed are already device tensors - resident in HBM - and pass through untouched
+        import itertools
         from pero_pretraining_amd.common.dataloader import DevicePrefetcher
-        from pero_pretraining_amd.masked_pretraining.batch_operator import BatchOperator
-        bop = BatchOperator(device, 0.15)
-        rng = np.random.default_rng(99 + rank)
-        S = CFG["width"] // CFG["patch"]
-        host = [{"images": rng.integers(0, 256, (args.batch, CFG["height"], CFG["width"], CFG["channels"]), dtype=np.uint8),
-                 "labels": rng.integers(0, CFG["vocab"], (args.batch, S)).astype(np.int64)} for _ in range(2)]
-        n_total = 2 + REPEATS * args.steps
-        pf = DevicePrefetcher((host[i % 2] for i in range(n_total + 1)), bop, device)
-        it = iter(pf)
+        feed = iter(DevicePrefetcher(({"images": b["images"], "labels": b["labels"]} for b in itertools.cycle(batches)),
+                                     trainer.batch_operator, device))
 
-        def step_h2d(i):
+        def step(i):
             sched.update_learning_rate(i)
-            images, labels, mask = next(it)
+            images, labels, mask = next(feed)
             return trainer.train_step_prepared(images, labels, mask)
 
-        for i in range(2):
-            step_h2d(i)
-        el, reps, _ = timer.median(step_h2d, args.steps, first=2)
-        with_prepare = {"value": round(world * args.batch * args.steps / el, 2), "unit": "lines/s", "ms_per_step": round(el / args.steps * 1e3, 3),
-                        "repeats_ms_per_step": [round(e / args.steps * 1e3, 3) for e in reps],
-                        "h2d_bytes_per_step": int(host[0]["images"].nbytes + host[0]["labels"].nbytes + args.batch * S * 8),
-                        "note": "prepare_batch inside the timed step: numpy mask draw on the host (masked_pretraining/batch_operator.py:27-32), "
-                                "uint8 batch + labels + mask from pinned host memory on a copy stream, double-buffered (common/dataloader.DevicePrefetcher)"}
-        del pf, it, host
+        def step_resident(i):
+            sched.update_learning_rate(i)
+            b = batches[i % len(batches)]
+            return trainer.train_step_prepared(b["images"], b["labels_dev"], b["mask_dev"])
 
-    # ---- reported beside the headline, never as `value`: the same step with the head and the loss on the masked positions only
-    option = None
-    if not args.masked_head and not args.no_options:
-        model.head_rows = "masked"
-        for i in range(3):
+        # ---- headline
+        for i in range(args.warmup):
             step(i)
-        el, reps, _ = timer.median(step, args.steps, first=3)
-        option = {"head_rows": "masked", "value": round(world * args.batch * args.steps / el, 2), "unit": "lines/s",
-                  "ms_per_step": round(el / args.steps * 1e3, 3),
-                  "note": "same loss, gradients and update; the head (d -> V) and the cross entropy run on the ~15 % masked "
-                          "positions instead of all (the reference computes and discards the rest); NOT the headline value"}
-        model.head_rows = "all"
-
-    roofline = None
-    if not args.no_roofline:
-        # every GEMM launch of two extra steps bracketed by HIP events on the stream it is launched on; the weight
-        # gradients are put back on the main stream for this leg so that no two kernels share the chip while timed
-        side_was = F.SIDE_STREAM_DW
-        F.SIDE_STREAM_DW = False
-        step(args.warmup + args.steps)
-        torch.cuda.synchronize()
-        ops.gemm_timeline = []
-        for i in range(2):
-            step(args.warmup + args.steps + 1 + i)
-        torch.cuda.synchronize()
-        tl, ops.gemm_timeline = ops.gemm_timeline, None
-        F.SIDE_STREAM_DW = side_was
-        per = {}
-        for e0, e1, fl, tag in tl:
-            d = per.setdefault(tag, [0.0, 0.0, 0])
-            d[0] += e0.elapsed_time(e1) * 1e-3
-            d[1] += fl
-            d[2] += 1
-        fast = {k: v for k, v in per.items() if k.startswith("gemm_bf16_tile")}
-        tsum = sum(v[0] for v in fast.values()) or 1e-30
-        fsum = sum(v[1] for v in fast.values())
-        nl = sum(v[2] for v in fast.values()) or 1
-        ach = fsum / tsum / 1e12
-        roofline = {"bound": "mfma",
-                    "kernel": "bf16 MFMA tile GEMM gemm_bf16_e256 (eight-phase persistent 256x256x64: forward, input gradients with fused "
-                              "epilogues, split-K weight gradients)",
-                    "achieved": round(ach, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4),
-                    "traffic": pmc_traffic(args.batch), "launches_per_step": nl // 2, "avg_launch_us": round(tsum / nl * 1e6, 2),
-                    "gflop_per_launch": round(fsum / nl / 1e9, 3),
-                    "gemm_time_share_of_step": round((tsum / 2) / (elapsed / args.steps), 3),
-                    "by_layout": {k: {"tflops": round(v[1] / v[0] / 1e12, 1), "ms_per_step": round(v[0] / 2 * 1e3, 3),
-                                      "launches_per_step": v[2] // 2} for k, v in sorted(per.items())}}
-
-    legs = None
-    if not args.no_legs and world == 1:
-        # free the masked model's 48 GB of saved activations first
-        del batches, row_lists
-        torch.cuda.empty_cache()
-        legs = {"config3_vq_argmin": leg_config3(timer, device),
-                "config4_vicreg_step": leg_joint(timer, device, "vicreg", 128, 5),
-                "config5_ntxent_step": leg_joint(timer, device, "ntxent", 128, 5)}
-
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline()
-
-    if rank == 0:
-        out = {
-            "metric": "text-line images/sec (masked-ViT step)", "value": round(lines_per_s, 2), "unit": "lines/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "masked pretraining step, 12-layer d=512 h=4 ff=2048 ViT, V=4096, 40x2048 u8 lines "
+        elapsed, repeats, loss = timer.median(step, args.steps, args.repeats, first=args.warmup)
+        final_loss = float(loss)
+        lines_per_s = world * args.batch * args.steps / elapsed
+        step_flops = flops_per_line()
+        exec_flops = flops_per_line(masked_frac=0.15) if (args.head_backward == "masked" and not args.masked_head) else step_flops
+        out.update({
+            "value": round(lines_per_s, 2), "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "config": {"workload": "masked pretraining step incl. prepare_batch, 12-layer d=512 h=4 ff=2048 ViT, V=4096, 40x2048 u8 lines "
                                    "(BASELINE.json configs[1])",
-                       "lines_per_gpu": args.batch, "global_batch": args.batch * world, "seq_len": CFG["width"] // CFG["patch"],
+                       "lines_per_gpu": args.batch, "global_batch": args.batch * world, "seq_len": S,
                        "parallelism": f"dp{world}", "optimizer": "fused Adam (f32 master weights)",
-                       "weight_gradients_on_side_stream": bool(F.SIDE_STREAM_DW), "head_rows": head_rows,
-                       "gflop_per_line_step": round(step_flops / 1e9, 3)},
-            "protocol": {"repeats": REPEATS, "statistic": "median", "repeats_ms_per_step": [round(e / args.steps * 1e3, 3) for e in repeats],
-                         "inputs": "resident in HBM"},
+                       "weight_gradients_on_side_stream": bool(F.SIDE_STREAM_DW), "head_rows": model.head_rows,
+                       "head_backward": args.head_backward,
+                       "gflop_per_line_step": round(step_flops / 1e9, 3), "gflop_per_line_step_executed": round(exec_flops / 1e9, 3)},
+            "protocol": {"repeats": args.repeats, "statistic": "median", "repeats_ms_per_step": [round(e / args.steps * 1e3, 3) for e in repeats],
+                         "inputs": "uint8 line images resident in HBM; labels from the host and the mask drawn on the host inside the timed "
+                                   "step (BatchOperator.prepare_batch)"},
             "distributed": {"world_size": dist.get_world_size() if dist.is_initialized() else 1, "backend": backend,
+                            "self_launched": bool(os.environ.get("PERO_BENCH_SELF_LAUNCHED")),
                             "gradient_all_reduce": "bucketed, overlapped with backward" if dist.is_initialized() and not args.dp_no_overlap else
                                                    ("after backward" if dist.is_initialized() else None)},
-            "step_mfma_frac": round(lines_per_s / world * step_flops / (BF16_MFMA_PEAK_TFLOPS * 1e12), 4),
-            "final_loss": round(final_loss, 5),
-            "roofline": roofline, "cpu_baseline": cpu, "with_prepare_batch": with_prepare, "option_masked_head": option, "legs": legs,
-        }
-        if real_stdout is None:
-            print(json.dumps(out))
+            # formula FLOPs (3F per line) and EXECUTED FLOPs (head backward on the masked rows only): the MFMA fraction of the
+            # step is computed from the executed count - multiplying by exact zeros is not work
+            "step_mfma_frac": round(lines_per_s / world * exec_flops / (BF16_MFMA_PEAK_TFLOPS * 1e12), 4),
+            "step_mfma_frac_formula_flops": round(lines_per_s / world * step_flops / (BF16_MFMA_PEAK_TFLOPS * 1e12), 4),
+            "final_loss": round(final_loss, 5)})
+
+        if not args.no_options and not args.masked_head:
+            reps = min(args.repeats, 3)
+            # ---- the same step with labels and mask resident too (train_step_prepared only: rounds 1-2's `value`)
+            for i in range(2):
+                step_resident(i)
+            el, rp, _ = timer.median(step_resident, args.steps, reps, first=2)
+            out["resident_step"] = {"value": round(world * args.batch * args.steps / el, 2), "unit": "lines/s", "ms_per_step": round(el / args.steps * 1e3, 3),
+                                    "repeats_ms_per_step": [round(e / args.steps * 1e3, 3) for e in rp],
+                                    "note": "prepare_batch outside the timed region (mask pre-drawn, labels resident)"}
+            # ---- PCIe-inclusive: the uint8 batch from pinned host memory on a copy stream, double-buffered against the previous step
+            from pero_pretraining_amd.common.dataloader import DevicePrefetcher
+            rng = np.random.default_rng(99 + rank)
+            host = [{"images": rng.integers(0, 256, (args.batch, CFG["height"], CFG["width"], CFG["channels"]), dtype=np.uint8),
+                     "labels": rng.integers(0, CFG["vocab"], (args.batch, S)).astype(np.int64)} for _ in range(2)]
+            n_total = 2 + reps * args.steps
+            it = iter(DevicePrefetcher((host[i % 2] for i in range(n_total + 1)), trainer.batch_operator, device))
+
+            def step_h2d(i):
+                sched.update_learning_rate(i)
+                images, labels, mask = next(it)
+                return trainer.train_step_prepared(images, labels, mask)
+
+            for i in range(2):
+                step_h2d(i)
+            el, rp, _ = timer.median(step_h2d, args.steps, reps, first=2)
+            out["with_h2d"] = {"value": round(world * args.batch * args.steps / el, 2), "unit": "lines/s", "ms_per_step": round(el / args.steps * 1e3, 3),
+                               "repeats_ms_per_step": [round(e / args.steps * 1e3, 3) for e in rp],
+                               "h2d_bytes_per_step": int(host[0]["images"].nbytes + host[0]["labels"].nbytes + args.batch * S * 8),
+                               "note": "PCIe-inclusive (never `value`): uint8 batch + labels + mask from pinned host memory on a copy stream, "
+                                       "double-buffered (common/dataloader.DevicePrefetcher)"}
+            del it, host
+            # ---- option: head forward + loss on the masked positions only
+            model.head_rows = "masked"
+            for i in range(3):
+                step(i)
+            el, rp, _ = timer.median(step, args.steps, reps, first=3)
+            out["option_masked_head"] = {"head_rows": "masked", "value": round(world * args.batch * args.steps / el, 2), "unit": "lines/s",
+                                         "ms_per_step": round(el / args.steps * 1e3, 3),
+                                         "note": "same loss, gradients and update; the head FORWARD too runs on the ~15 % masked positions only "
+                                                 "(the reference computes and discards the rest); NOT the headline value"}
+            model.head_rows = "all"
+
+        if not args.no_roofline:
+            per = timed_gemms(lambda n: [step(args.warmup + 7 + k) for k in range(n)], 2)
+            traffic, src = pmc_traffic(args.batch)
+            out["roofline"] = gemm_roofline(per, 2, elapsed / args.steps, traffic)
+            out["roofline"]["traffic_source"] = f"profiles/{src} (csrc_sha256 {csrc_hash()})" if src else None
+        del batches, model, opt, trainer
+        torch.cuda.empty_cache()   # the masked model's 48 GB of saved activations
+
+    if not args.no_legs:
+        reps = min(args.repeats, 3)
+        legs = {}
+        if world == 1:
+            legs["config3_vq_argmin"] = leg_config3(timer, device)
+            legs["config4_vicreg_step"] = leg_joint(timer, device, "vicreg", 128, 5, reps, world, rank)
+            legs["config5_ntxent_step"] = leg_joint(timer, device, "ntxent", 512, 3, reps, world, rank)
         else:
-            sys.stdout.flush()
-            os.write(real_stdout, (json.dumps(out) + "\n").encode())
+            legs["config4_vicreg_dp"] = leg_joint(timer, device, "vicreg", 128, 5, reps, world, rank)
+            legs["config4_vicreg_dp_global_statistics"] = leg_joint(timer, device, "vicreg", 128, 5, reps, world, rank, variant="global")
+            legs["config5_ntxent_dp_cross_rank_negatives"] = leg_joint(timer, device, "ntxent", 512, 3, reps, world, rank, variant="cross")
+        out["legs"] = legs
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.legs_only:
+        out["cpu_baseline"] = cpu_baseline()
+    emit(out)
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
+def plumbing_test(args, world, rank, emit):
+    """CPU rehearsal of everything around the GPU work (tests/test_parallel_gloo.py): rank environment, gloo process group, the
+    barrier-bracketed max-over-ranks timing, the one JSON line through the saved descriptor and the self-launch relay."""
+    dev = torch.device("cpu")
+    if "RANK" in os.environ:
+        dist.init_process_group("gloo")
+    timer = Timer(dev)
+    x = torch.zeros(4)
+
+    def step(i):
+        y = x + 1.0
+        if dist.is_initialized():
+            dist.all_reduce(y)
+        if rank == world - 1:
+            time.sleep(0.002)   # the slowest rank sets the time
+        return y
+
+    for i in range(args.warmup):
+        step(i)
+    el, reps, y = timer.median(step, args.steps, args.repeats, first=args.warmup)
+    emit({"metric": "plumbing", "value": round(world * args.steps / el, 2), "unit": "steps/s", "n_gpus": world, "steps": args.steps,
+          "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 3),
+          "distributed": {"world_size": dist.get_world_size() if dist.is_initialized() else 1,
+                          "backend": dist.get_backend() if dist.is_initialized() else None,
+                          "self_launched": bool(os.environ.get("PERO_BENCH_SELF_LAUNCHED"))},
+          "all_reduce_check": float(y[0]), "repeats": len(reps)})
     if dist.is_initialized():
         dist.destroy_process_group()
 

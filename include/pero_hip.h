@@ -9,7 +9,9 @@
  *
  * Conventions
  *   - every pointer is a DEVICE pointer owned by the caller (workspaces included); the library never
- *     allocates, frees or synchronises;
+ *     allocates, frees, copies from the host or synchronises (its only host-side state: pero_set_option's
+ *     knobs, and two immutable values initialised once, thread-safely: the device's CU count and each
+ *     kernel's dynamic-LDS limit);
  *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it;
  *   - `dtype`: PERO_F32 (parity mode, exact f32 MFMA / VALU arithmetic) or PERO_BF16 (bf16 storage
  *     and MFMA operands, f32 accumulation, f32 statistics);
@@ -33,7 +35,9 @@ extern "C" {
 
 /* epilogue / mode flags of pero_gemm */
 #define PERO_GEMM_RELU 1        /* C = max(C, 0) after bias/residual */
-#define PERO_GEMM_ATOMIC 2      /* f32 C only: atomically add the tile into C (split-K safe) */
+#define PERO_GEMM_ATOMIC 2      /* f32 C only: the product is ADDED into C (split-K safe; several streams may add into one C).  With a
+                                 * `workspace` of pero_gemm_workspace_bytes() the slices of a tile are summed in slice order before the
+                                 * one add per element: bit-reproducible from run to run when C has a single writer */
 #define PERO_GEMM_ACCUM 4       /* f32 C only: C += result (non-atomic) */
 #define PERO_GEMM_TRANS_A 8     /* A is stored [K][M] (lda = row pitch of that storage) */
 #define PERO_GEMM_TRANS_B 16    /* B is stored [K][N]; default B is stored [N][K] (Linear weight layout) */
@@ -59,8 +63,9 @@ int pero_abi_version(void);
  * family, table in csrc/gemm.hip), "gemm_e256_min" (192: stored products with at least that many 256x256 tiles take the eight-phase
  * kernel; 0 = never), "gemm_e_splitk_min" (4), "gemm_e_var" (diagnostic builds of that kernel), "splitk_items" (512), "splitk_xcd" (1),
  * "splitk_nearest" (0), "attn_bwd_pair" (1: the attention backward with D handed in runs as one launch, csrc/attention.hip), "splitk_workspace" (1: the split-K
- * products of the eight-phase kernel leave partial tiles in a 64 MiB workspace per stream, summed in slice order by a second kernel - deterministic;
- * 0: f32 atomics), "splitk_table" (1: unaligned slice counts hand their work items out XCD by XCD).  Process-wide; not meant to be changed while products are in flight. */
+ * products of the eight-phase kernel leave partial tiles in the caller's `workspace`, summed in slice order by a second kernel - deterministic;
+ * 0: f32 atomics even when a workspace is passed), "splitk_table" (1: unaligned slice counts hand their work items out XCD by XCD).  Process-wide; not
+ * meant to be changed while products are in flight. */
 int pero_set_option(const char* name, int value);
 
 /* ---- front end ------------------------------------------------------------------------------
@@ -86,12 +91,20 @@ int pero_apply_mask_f32(float* images_nchw, const int64_t* mask, const float* ti
  * joint_embedding_pretraining/losses.py:42,77 and their autograd backward products.
  * Batch b = bo * batch_inner + bi; operand base offset = bo * s?o + bi * s?i (elements).
  * in_dtype: A, B (and residual, gate); out_dtype: C.  bias is f32.  k_split > 1 needs PERO_GEMM_ATOMIC;
- * k_split == 0 with PERO_GEMM_ATOMIC lets the library choose tile size and split. */
+ * k_split == 0 with PERO_GEMM_ATOMIC lets the library choose tile size and split.
+ * workspace (device, 16-byte aligned, may be null) / workspace_bytes: scratch for this ONE call, owned by the caller and free again
+ * when the work enqueued by the call has run (calls on one stream may share it; concurrent streams need one each).  Only the split-K
+ * weight-gradient products use it (partial tiles, see PERO_GEMM_ATOMIC); with less than pero_gemm_workspace_bytes() they add with
+ * f32 atomics instead - same value up to the order of the additions. */
 int pero_gemm(const void* A, const void* B, void* C, const float* bias, const void* residual, const void* gate,
               int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int64_t ldg,
               int64_t batch, int64_t batch_inner,
               int64_t sAo, int64_t sAi, int64_t sBo, int64_t sBi, int64_t sCo, int64_t sCi,
-              float alpha, int flags, int k_split, int in_dtype, int out_dtype, void* stream);
+              float alpha, int flags, int k_split, int in_dtype, int out_dtype, void* workspace, int64_t workspace_bytes,
+              void* stream);
+/* bytes of `workspace` with which pero_gemm runs the product of this shape / flags / k_split deterministically (0: it needs none).
+ * Depends on the arguments and the pero_set_option knobs only (no device query). */
+int64_t pero_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K, int64_t batch, int flags, int k_split, int in_dtype, int out_dtype);
 
 /* ---- LayerNorm (+ positional encoding) --------------------------------------------------------------
  * y = (x - mean) * rstd * gamma + beta (+ pe[offsets[row / S] + row % S]) ; rows x d.
@@ -144,6 +157,13 @@ int pero_masked_ce_fwd(const void* logits, const int64_t* labels, const int64_t*
 int pero_masked_ce_bwd(const void* logits, const int64_t* labels, const int64_t* mask, float unmasked_weight,
                        const float* dloss, const float* work, void* dlogits, int64_t rows, int64_t V, int dtype,
                        void* stream);
+/* The same gradient in COMPACT form: dlogits_rows (dtype, n_rows_out x V) row i = the gradient row of logits row index[i] for
+ * i < n_idx (bit-identical to row index[i] of pero_masked_ce_bwd's result), zero rows for n_idx <= i < n_rows_out (padding up to whole
+ * GEMM tiles).  With unmasked_weight "None" every row outside mask == 1 of the dense gradient is an exact zero, so the head's
+ * backward products (masked_pretraining/model.py:60-61 through autograd) run on the listed rows alone.  index: int64 device list. */
+int pero_masked_ce_bwd_rows(const void* logits, const int64_t* labels, const int64_t* mask, float unmasked_weight,
+                            const float* dloss, const float* work, const int64_t* index, int64_t n_idx, int64_t n_rows_out,
+                            void* dlogits_rows, int64_t rows, int64_t V, int dtype, void* stream);
 
 /* ---- reductions / elementwise ---------------------------------------------------------------------- */
 /* out[n] += sum_m x[m][n]  (bias gradients); out f32 */

@@ -5,6 +5,7 @@ the first op, and every non-zero return code becomes a Python exception carrying
 """
 import ctypes
 import os
+import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpero_hip.so")
@@ -28,7 +29,7 @@ SIGNATURES = {
     "pero_add_rows2d": [_vp, _vp, _i64, _i64, _i64, _i64, _vp],
     "pero_apply_mask_f32": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp],
     "pero_gemm": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
-                  _i64, _i64, _i64, _i64, _i64, _i64, _f32, _i32, _i32, _i32, _i32, _vp],
+                  _i64, _i64, _i64, _i64, _i64, _i64, _f32, _i32, _i32, _i32, _i32, _vp, _i64, _vp],
     "pero_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _f32, _i32, _vp],
     "pero_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp],
     "pero_attention_fwd": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp],
@@ -37,6 +38,7 @@ SIGNATURES = {
     "pero_softmax_bwd": [_vp, _vp, _vp, _i64, _i64, _f32, _i32, _vp],
     "pero_masked_ce_fwd": [_vp, _vp, _vp, _f32, _vp, _vp, _i64, _i64, _i32, _vp],
     "pero_masked_ce_bwd": [_vp, _vp, _vp, _f32, _vp, _vp, _vp, _i64, _i64, _i32, _vp],
+    "pero_masked_ce_bwd_rows": [_vp, _vp, _vp, _f32, _vp, _vp, _vp, _i64, _i64, _vp, _i64, _i64, _i32, _vp],
     "pero_colsum": [_vp, _vp, _i64, _i64, _i64, _i32, _vp],
     "pero_cast_f32_bf16": [_vp, _vp, _i64, _vp],
     "pero_transpose_multi": [_vp, _vp, _vp, _i64, _i64, _vp],
@@ -69,24 +71,35 @@ class PeroHipError(RuntimeError):
     pass
 
 
+ABI_VERSION = 2
 _lib = None
+_lib_lock = threading.Lock()
 
 
 def lib():
     """Load (once) and return the ctypes handle.  Raises if the HIP library has not been built."""
     global _lib
-    if _lib is None:
+    if _lib is not None:
+        return _lib
+    with _lib_lock:
+        if _lib is not None:
+            return _lib
         if not os.path.exists(LIB_PATH):
             raise PeroHipError(
                 f"{LIB_PATH} not found: build it with `make -C {os.path.join(_HERE, 'csrc')}` "
                 "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
         h = ctypes.CDLL(LIB_PATH)
-        h.pero_last_error.restype = ctypes.c_char_p
-        h.pero_last_error.argtypes = []
         h.pero_abi_version.restype = ctypes.c_int
         h.pero_abi_version.argtypes = []
+        if h.pero_abi_version() != ABI_VERSION:
+            raise PeroHipError(f"{LIB_PATH} has ABI version {h.pero_abi_version()}, this package binds version {ABI_VERSION}: rebuild it "
+                               f"(`make -C {os.path.join(_HERE, 'csrc')}`)")
+        h.pero_last_error.restype = ctypes.c_char_p
+        h.pero_last_error.argtypes = []
         h.pero_set_option.restype = ctypes.c_int
         h.pero_set_option.argtypes = [ctypes.c_char_p, ctypes.c_int]
+        h.pero_gemm_workspace_bytes.restype = ctypes.c_int64
+        h.pero_gemm_workspace_bytes.argtypes = [_i64, _i64, _i64, _i64, _i32, _i32, _i32, _i32]
         for name, args in SIGNATURES.items():
             fn = getattr(h, name)
             fn.restype = ctypes.c_int

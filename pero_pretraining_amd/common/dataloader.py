@@ -215,7 +215,7 @@ class DevicePrefetcher:
                             buf = self._pinned[slot][key] = torch.empty(o.shape, dtype=torch.from_numpy(o[:0]).dtype, pin_memory=True)
                         buf.numpy()[...] = o
                         t = buf.to(self.device, non_blocking=True)
-                        t._pero_host = o
+                        t._pero_host = np.array(o, copy=True)   # private: `o` may alias a buffer the producer reuses
                         conv.append(t)
                     else:
                         conv.append(o)

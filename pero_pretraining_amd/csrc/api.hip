@@ -12,4 +12,4 @@ void pero_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* pero_last_error(void) { return g_err; }
-extern "C" int pero_abi_version(void) { return 1; }
+extern "C" int pero_abi_version(void) { return 2; }  // 2: pero_gemm takes a caller-owned workspace (round 3)

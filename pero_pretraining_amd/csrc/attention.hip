@@ -225,8 +225,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_k(const bf16raw* qkv, bf16raw
 
 // heads per workgroup: as many as keep >= 2 workgroups per CU busy
 static int attn_heads_per_block(long long N, long long S, long long nh) {
-  static int num_cus = 0;
-  if (!num_cus) { hipDeviceProp_t prop; int dev = 0; hipGetDevice(&dev); hipGetDeviceProperties(&prop, dev); num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256; }
+  const int num_cus = pero_num_cus();
   int hpb = 1;
   for (int cand = (int)nh; cand >= 1; cand--)
     if (nh % cand == 0 && N * (S / 128) * (nh / cand) >= 2LL * num_cus) { hpb = cand; break; }
@@ -239,8 +238,7 @@ extern "C" int pero_attention_fwd(const void* qkv, void* out, float* lse, int64_
   PERO_REQUIRE(dtype == PERO_BF16 && head_dim == 128 && S % 128 == 0 && S > 0 && N > 0 && num_heads > 0,
                "pero_attention_fwd: fused kernel needs bf16, head_dim 128, S %% 128 == 0 (got hd=%lld S=%lld)", (long long)head_dim, (long long)S);
   PERO_REQUIRE(aligned16(qkv) && aligned16(out), "pero_attention_fwd: 16-byte alignment");
-  static bool attr = false;
-  if (!attr) { hipFuncSetAttribute((const void*)attn_fwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * AT_TILE_BYTES); attr = true; }
+  PERO_LDS_ATTR(attn_fwd_k, 2 * AT_TILE_BYTES);
   const float c = (float)(1.4426950408889634 / sqrt((double)head_dim));
   const int hpb = attn_heads_per_block(N, S, num_heads);
   hipLaunchKernelGGL(attn_fwd_k, dim3((unsigned)(N * (num_heads / hpb) * (S / 128))), dim3(256), 2 * AT_TILE_BYTES, (hipStream_t)stream,
@@ -616,14 +614,9 @@ extern "C" int pero_attention_bwd(const void* qkv, const void* out, const void* 
                "pero_attention_bwd: fused kernel needs bf16, head_dim 128, S %% 128 == 0");
   PERO_REQUIRE(aligned16(qkv) && (!out || aligned16(out)) && aligned16(dout) && aligned16(dqkv), "pero_attention_bwd: 16-byte alignment");
   PERO_REQUIRE(!dbias || work, "pero_attention_bwd: dbias needs the partial-sum workspace");
-  static bool attr = false;
-  if (!attr) {
-    hipFuncSetAttribute((const void*)attn_bwd_dq_k, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * AT_TILE_BYTES);
-    hipFuncSetAttribute((const void*)attn_bwd_dkv2_k, hipFuncAttributeMaxDynamicSharedMemorySize, AT_DKV2_LDS);
-    hipFuncSetAttribute((const void*)attn_bwd_pair_k, hipFuncAttributeMaxDynamicSharedMemorySize,
-                        AT_DKV2_LDS > 2 * AT_TILE_BYTES ? AT_DKV2_LDS : 2 * AT_TILE_BYTES);
-    attr = true;
-  }
+  PERO_LDS_ATTR(attn_bwd_dq_k, 2 * AT_TILE_BYTES);
+  PERO_LDS_ATTR(attn_bwd_dkv2_k, AT_DKV2_LDS);
+  PERO_LDS_ATTR(attn_bwd_pair_k, AT_DKV2_LDS > 2 * AT_TILE_BYTES ? AT_DKV2_LDS : 2 * AT_TILE_BYTES);
   const float scale = (float)(1.0 / sqrt((double)head_dim));
   const float c = (float)(1.4426950408889634 / sqrt((double)head_dim));
   hipStream_t st = (hipStream_t)stream;

@@ -101,3 +101,21 @@ void pero_set_error(const char* fmt, ...);
     }                                                                               \
   } while (0)
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+// Host-side state of the library is limited to these two immutable, once-initialised values (C++11 static initialisation is
+// thread-safe: the entry points are called from autograd worker threads) and the pero_set_option knobs.
+//  * a kernel's dynamic-LDS limit above 64 KiB, set once per process and kernel
+#define PERO_LDS_ATTR(kernel_, bytes_)                                                                                              \
+  do {                                                                                                                              \
+    static const hipError_t attr_once_ = hipFuncSetAttribute((const void*)(kernel_), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes_)); \
+    (void)attr_once_;                                                                                                               \
+  } while (0)
+//  * the CU count of the process's device (one process per GPU)
+static inline int pero_num_cus() {
+  static const int n = [] {
+    hipDeviceProp_t prop;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+    return prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }();
+  return n;
+}

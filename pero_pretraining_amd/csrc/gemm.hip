@@ -394,14 +394,32 @@ static int gemm_dispatch(const void* A, const void* B, void* C, const float* bia
                          int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int64_t ldg,
                          int64_t batch, int64_t batch_inner,
                          int64_t sAo, int64_t sAi, int64_t sBo, int64_t sBi, int64_t sCo, int64_t sCi,
-                         float alpha, int flags, int k_split, int in_dtype, int out_dtype, void* stream, bool* colsum_fused);
+                         float alpha, int flags, int k_split, int in_dtype, int out_dtype, void* workspace, int64_t workspace_bytes,
+                         void* stream, bool* colsum_fused);
+
+// does a split-K product of this shape take the eight-phase kernel (whose partial tiles can go to a caller-owned workspace)?
+static bool splitk_takes_e256(int64_t M, int64_t N, int64_t K, int flags) {
+  const bool can256 = M % 256 == 0 && N % 256 == 0 && !(flags & PERO_GEMM_TILE128) && g_gemm_policy != 1;
+  const long long t256 = can256 ? (M / 256) * (N / 256) : 0;
+  return can256 && K % 64 == 0 && K >= 128 &&
+         (g_gemm_policy == 20 || (g_gemm_policy == 0 && ((flags & PERO_GEMM_TILE256) || (g_gemm_e256_min > 0 && K >= 32768 && t256 >= g_gemm_e_splitk_min))));
+}
+extern "C" int64_t pero_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K, int64_t batch, int flags, int k_split, int in_dtype,
+                                             int out_dtype) {
+  if (!(flags & PERO_GEMM_ATOMIC) || batch != 1 || in_dtype != PERO_BF16 || out_dtype != PERO_F32 || (flags & PERO_GEMM_FORCE_GENERIC) || M <= 0 ||
+      N <= 0 || K <= 0 || !splitk_takes_e256(M, N, K, flags))
+    return 0;
+  return pero_gemm_e256_splitk_ws_bytes(M, N, K, k_split);
+}
 
 extern "C" int pero_gemm(const void* A, const void* B, void* C, const float* bias, const void* residual, const void* gate,
                          int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int64_t ldg,
                          int64_t batch, int64_t batch_inner,
                          int64_t sAo, int64_t sAi, int64_t sBo, int64_t sBi, int64_t sCo, int64_t sCi,
-                         float alpha, int flags, int k_split, int in_dtype, int out_dtype, void* stream) {
+                         float alpha, int flags, int k_split, int in_dtype, int out_dtype, void* workspace, int64_t workspace_bytes,
+                         void* stream) {
   bool fused = false;
+  PERO_REQUIRE(workspace_bytes >= 0 && (workspace || workspace_bytes == 0), "pero_gemm: workspace_bytes without a workspace");
   if (flags & PERO_GEMM_COLSUM)
     PERO_REQUIRE(bias && batch == 1 && !(flags & (PERO_GEMM_ATOMIC | PERO_GEMM_ACCUM | PERO_GEMM_ROWDOT)),
                  "pero_gemm: PERO_GEMM_COLSUM needs the output pointer in `bias`, one problem, a stored result");
@@ -409,7 +427,7 @@ extern "C" int pero_gemm(const void* A, const void* B, void* C, const float* bia
     PERO_REQUIRE(bias && gate && batch == 1 && out_dtype == PERO_BF16 && N % 128 == 0 && !(flags & (PERO_GEMM_ATOMIC | PERO_GEMM_ACCUM)),
                  "pero_gemm: PERO_GEMM_ROWDOT needs the output pointer in `bias`, the second matrix in `gate`, bf16 C, N %% 128 == 0");
   const int rc = gemm_dispatch(A, B, C, bias, residual, gate, M, N, K, lda, ldb, ldc, ldr, ldg, batch, batch_inner, sAo, sAi, sBo, sBi,
-                               sCo, sCi, alpha, flags, k_split, in_dtype, out_dtype, stream, &fused);
+                               sCo, sCi, alpha, flags, k_split, in_dtype, out_dtype, workspace, workspace_bytes, stream, &fused);
   if (rc != PERO_OK || !(flags & (PERO_GEMM_COLSUM | PERO_GEMM_ROWDOT)) || fused) return rc;
   // kernels without the fused epilogue: a pass over C
   if (flags & PERO_GEMM_ROWDOT) return pero_rowdot_blocks(C, gate, (float*)bias, M, N, ldc, ldg, stream);
@@ -420,7 +438,8 @@ static int gemm_dispatch(const void* A, const void* B, void* C, const float* bia
                          int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int64_t ldg,
                          int64_t batch, int64_t batch_inner,
                          int64_t sAo, int64_t sAi, int64_t sBo, int64_t sBi, int64_t sCo, int64_t sCi,
-                         float alpha, int flags, int k_split, int in_dtype, int out_dtype, void* stream, bool* colsum_fused) {
+                         float alpha, int flags, int k_split, int in_dtype, int out_dtype, void* workspace, int64_t workspace_bytes,
+                         void* stream, bool* colsum_fused) {
   PERO_REQUIRE(A && B && C, "pero_gemm: null operand");
   PERO_REQUIRE(M > 0 && N > 0 && K > 0 && batch > 0 && batch_inner > 0, "pero_gemm: bad sizes M=%lld N=%lld K=%lld batch=%lld",
                (long long)M, (long long)N, (long long)K, (long long)batch);
@@ -466,9 +485,8 @@ static int gemm_dispatch(const void* A, const void* B, void* C, const float* bia
     const int k_split_req = k_split;
     const bool auto_or = g_gemm_policy == 0;
     // the eight-phase persistent 256x256x64 kernel (gemm_e.hip): split-K weight gradients on long reductions ...
-    if (atomic && out_dtype == PERO_F32 && can256 &&
-        (g_gemm_policy == 20 || (auto_or && (force256 || (g_gemm_e256_min > 0 && K >= 32768 && t256 >= g_gemm_e_splitk_min)))) &&
-        pero_launch_gemm_e256(p, batch, k_split_req, ta, tb, true, st, -1)) {
+    if (atomic && out_dtype == PERO_F32 && batch == 1 && splitk_takes_e256(M, N, K, flags) &&
+        pero_launch_gemm_e256(p, batch, k_split_req, ta, tb, true, st, -1, workspace, workspace_bytes)) {
       PERO_CHECK_LAUNCH("pero_gemm(e256 split-K)");
       return PERO_OK;
     }
@@ -518,18 +536,13 @@ static int gemm_dispatch(const void* A, const void* B, void* C, const float* bia
       k_split = (int)((steps + per - 1) / per);
     }
     const long long nwork = (M / T_BM) * (N / T_BN) * batch * k_split;
-    static int num_cus = 0;
-    if (!num_cus) { hipDeviceProp_t prop; int dev = 0; hipGetDevice(&dev); hipGetDeviceProperties(&prop, dev); num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256; }
+    const int num_cus = pero_num_cus();
     const long long resident = 2LL * num_cus;  // 2 workgroups per CU (LDS-limited)
     dim3 grid((unsigned)(nwork < resident ? nwork : resident)), block(256);
     const int nbatch = (int)batch;
 #define LAUNCH_FAST(TA_, TB_, OF_)                                                                                        \
   do {                                                                                                                    \
-    static bool attr_set = false;                                                                                         \
-    if (!attr_set) {                                                                                                      \
-      hipFuncSetAttribute((const void*)gemm_bf16_t128<TA_, TB_, OF_>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES); \
-      attr_set = true;                                                                                                    \
-    }                                                                                                                     \
+    PERO_LDS_ATTR((gemm_bf16_t128<TA_, TB_, OF_>), T_LDS_BYTES);                                                          \
     hipLaunchKernelGGL((gemm_bf16_t128<TA_, TB_, OF_>), grid, block, T_LDS_BYTES, st, p, nbatch, nwork);                                 \
   } while (0)
     const bool of = out_dtype == PERO_F32;

@@ -31,4 +31,7 @@ bool pero_launch_gemm_o128(const GemmP& p, long long batch, int k_split, bool ta
 // host entry of the 256x128x32 eight-wave kernel (gemm_r.hip): stored products of small batches
 bool pero_launch_gemm_r256(const GemmP& p, long long batch, int k_split, bool ta, bool tb, bool out_f32, hipStream_t st);
 // host entry of the eight-phase ping-pong persistent 256x256x64 kernel (gemm_e.hip); var < 0: the "gemm_e_var" option
-bool pero_launch_gemm_e256(const GemmP& p, long long batch, int k_split, bool ta, bool tb, bool out_f32, hipStream_t st, int var = 0);
+// ws / ws_bytes: the caller's workspace for split-K partial tiles (pero_gemm's `workspace`); null: f32 atomics
+bool pero_launch_gemm_e256(const GemmP& p, long long batch, int k_split, bool ta, bool tb, bool out_f32, hipStream_t st, int var = 0,
+                           void* ws = nullptr, long long ws_bytes = 0);
+long long pero_gemm_e256_splitk_ws_bytes(long long M, long long N, long long K, int k_split);

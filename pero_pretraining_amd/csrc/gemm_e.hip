@@ -123,6 +123,32 @@ template <int EPI> struct ECnt {
   static constexpr int S_HALF = 8 + (EPI == EP_RELU_BITS ? 4 : 0) + (EPI == EP_ROWDOT ? 4 : 0);
 };
 
+// Work-item order for split-K slice counts that are no multiple of 8 (e.g. 12 tiles x 21 slices).  Workgroup T runs on XCD T & 7;
+// slice z belongs to XCD z % 8, and an XCD takes the (tile, slice) items of its own slices first, slice by slice, so that the tiles
+// which stream the same operand panels meet in one L2; what an XCD has too many of (an XCD with three slices has 36 items for 31-32
+// workgroups) goes to the XCDs with room.  In plain order (item = T) every XCD fetched every panel: K-tiles of 4.2 k cycles against
+// 3.6 k with aligned slices.  Computed per workgroup from (tiles, slices) alone - a few scalar loops - so no table, no allocation
+// and no host copy stand behind the product (round 2 kept a device table per shape in a process-wide cache).
+__device__ __forceinline__ void esplitk_xcd_item(int T, int tiles, int nsl, int& id, int& z) {
+  const int n = tiles * nsl, x = T & 7, k = T >> 3;
+  auto cnt = [&](int xx) { return tiles * ((nsl - xx + 7) / 8); };   // items of the slices z = xx, xx + 8, ... < nsl
+  auto cap = [&](int xx) { return (n - xx + 7) / 8; };               // workgroups T = xx, xx + 8, ... < n
+  int kk = k, xo = x;
+  if (k >= cnt(x)) {
+    // one of this XCD's free places: the q-th of all free places (in XCD order) takes the q-th surplus item (in XCD order)
+    int q = k - cnt(x);
+    for (int xx = 0; xx < x; xx++) { const int dfc = cap(xx) - cnt(xx); q += dfc > 0 ? dfc : 0; }
+    for (int xx = 0; xx < 8; xx++) {
+      const int sp = cnt(xx) - cap(xx);
+      if (sp <= 0) continue;
+      if (q < sp) { xo = xx; kk = cap(xx) + q; break; }
+      q -= sp;
+    }
+  }
+  z = xo + 8 * (kk / tiles);
+  id = kk % tiles;
+}
+
 template <bool TA, bool TB, int EPI, int VAR>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p, int ks) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -154,7 +180,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p, int ks) {
     // work item = (tile, k-slice); the slices of one XCD's workgroups are the same few (operand panels fetched once per L2)
     const int xcd = T & 7, r = T >> 3;
     int id, z;
-    if (ks < 0 && p.bias) { const unsigned e = ((const unsigned*)p.bias)[T]; id = (int)(e >> 8); z = (int)(e & 255u); }  // table (launcher)
+    if (ks < 0 && p.kchunk) esplitk_xcd_item(T, ntn * (int)(p.M / E_BM), -ks, id, z);  // any slice count, XCD by XCD
     else if (ks < 0) { id = T / (-ks); z = T % (-ks); }  // any slice count: plain order
     else if (ks >= 8) { const int per = ks >> 3; z = xcd * per + (r % per); id = r / per; }
     else { z = xcd % ks; id = r * (8 / ks) + xcd / ks; }
@@ -698,75 +724,49 @@ __global__ __launch_bounds__(256) void pero_splitk_reduce_k(const f4v* ws, float
   const int ha = idx >> 4, hb = (idx >> 3) & 1, i = (idx >> 1) & 3, j = idx & 1;
   const long long row = (long long)(tile / ntn) * E_BM + 128 * (wave >> 2) + 64 * ha + 16 * i + (lane & 15);
   const long long col = (long long)(tile % ntn) * E_BN + 64 * (wave & 3) + 32 * hb + 16 * j + 4 * (lane >> 4);
-  f4v* dst = (f4v*)(C + row * ldc + col);
-  *dst = *dst + sum * alpha;
-}
-// One workspace of 256 partial tiles (64 MiB) per stream that launches split-K products (at most four streams; a fifth, a launch
-// during stream capture before its workspace exists, or a failed allocation fall back to the atomic epilogue).
-static void* splitk_workspace(hipStream_t st, long long items) {
-  constexpr long long kItems = 256;
-  static struct { hipStream_t st; void* ptr; int dev; } slots[4];
-  static int nslots = 0;
-  if (items > kItems) return nullptr;
-  int dev = 0;
-  hipGetDevice(&dev);
-  for (int i = 0; i < nslots; i++)
-    if (slots[i].st == st && slots[i].dev == dev) return slots[i].ptr;
-  if (nslots == 4) return nullptr;
-  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return nullptr; }
-  void* ptr = nullptr;
-  if (hipMalloc(&ptr, (size_t)kItems * E_BM * E_BN * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-  slots[nslots].st = st; slots[nslots].ptr = ptr; slots[nslots].dev = dev;
-  nslots++;
-  return ptr;
+  // one add per address and launch: with a single writer of C the result does not depend on any order (reproducible); two streams
+  // that accumulate into the same C (PERO_GEMM_ATOMIC allows it) stay race-free
+  float* dst = C + row * ldc + col;
+#pragma unroll
+  for (int e = 0; e < 4; e++) atomicAdd(dst + e, sum[e] * alpha);
 }
 __global__ __launch_bounds__(256) void pero_zero16_k(f4v* p, long long n16) {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long long)gridDim.x * 256) p[i] = (f4v){0.f, 0.f, 0.f, 0.f};
 }
 int g_gemm_splitk_ws = 1;   // pero_set_option("splitk_workspace", 0): atomic epilogue
-// Work-item table for slice counts that are no multiple of 8 (e.g. 12 tiles x 21 slices): workgroup T runs on XCD T & 7; slice z belongs
-// to XCD z % 8, and an XCD takes the (tile, slice) items of its own slices first, slice by slice, so that the tiles which stream the same
-// operand panels meet in one L2; what an XCD has too many of (an XCD with three slices has 36 items for 31-32 workgroups) goes to the
-// XCDs with room.  In plain order (item = T) every XCD fetched every panel: K-tiles of 4.2 k cycles against 3.6 k with aligned slices.
-// Tables live in device memory, one per (tiles, slices) pair, made at the first launch of that shape (not during stream capture).
-static const unsigned* splitk_item_table(hipStream_t st, int tiles, int nsl) {
-  static struct { int tiles, nsl, dev; unsigned* ptr; } cache[16];
-  static int ncache = 0;
-  int dev = 0;
-  hipGetDevice(&dev);
-  for (int i = 0; i < ncache; i++)
-    if (cache[i].tiles == tiles && cache[i].nsl == nsl && cache[i].dev == dev) return cache[i].ptr;
-  const int n = tiles * nsl;
-  if (ncache == 16 || n > 4096 || nsl > 255) return nullptr;
-  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return nullptr; }
-  std::vector<unsigned> tab((size_t)n, 0xffffffffu), pool;
-  std::vector<std::vector<unsigned>> own(8);
-  for (int z = 0; z < nsl; z++)
-    for (int id = 0; id < tiles; id++) own[z & 7].push_back(((unsigned)id << 8) | (unsigned)z);
-  for (int x = 0; x < 8; x++) {
-    const int cap = (n - x + 7) / 8;   // workgroups T = x, x + 8, ... < n
-    while ((int)own[x].size() > cap) { pool.push_back(own[x].back()); own[x].pop_back(); }
-  }
-  for (int x = 0; x < 8; x++) {
-    const int cap = (n - x + 7) / 8;
-    while ((int)own[x].size() < cap && !pool.empty()) { own[x].push_back(pool.back()); pool.pop_back(); }
-    for (int k = 0; k < (int)own[x].size(); k++) tab[(size_t)k * 8 + x] = own[x][k];
-  }
-  for (unsigned e : tab) if (e == 0xffffffffu) return nullptr;   // (cannot happen: the capacities add up to n)
-  unsigned* ptr = nullptr;
-  if (hipMalloc((void**)&ptr, (size_t)n * sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-  if (hipMemcpy(ptr, tab.data(), (size_t)n * sizeof(unsigned), hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); hipFree(ptr); return nullptr; }
-  cache[ncache].tiles = tiles; cache[ncache].nsl = nsl; cache[ncache].dev = dev; cache[ncache].ptr = ptr;
-  ncache++;
-  return ptr;
-}
 int g_gemm_splitk_table = 1;   // pero_set_option("splitk_table", 0): plain item order for unaligned slice counts
 
-// Qualifies: one problem (batch 1), no split-K, bf16 stored output, alpha == 1, M % 256 == N % 256 == K % 64 == 0, K >= 128.
+// Slice count of a split-K product on this kernel (k_split <= 0: the library chooses) and whether the slices can be aligned to the XCDs.
+static int e256_splitk_slices(long long tiles, long long steps, int k_split, bool* xcd_ok) {
+  int ks = k_split;
+  if (ks <= 0) {  // the library chooses: one round of workgroups over the CUs
+    ks = (int)(256 / tiles);
+    if (ks >= 8) ks = (ks / 8) * 8; else if (ks >= 4) ks = 4; else if (ks >= 2) ks = 2; else ks = 1;
+    // an XCD-aligned slice count (one slice set per XCD: operand panels fetched once per L2) when it fills >= 90 % of the CUs
+    // that the plain count fills, else the plain count
+    int kx = (int)(256 / tiles);
+    kx = kx < 1 ? 1 : kx;
+    if (ks * tiles * 10 < kx * tiles * 9) ks = kx;
+  }
+  while (ks > 1 && steps / ks < 2) ks--;
+  if (xcd_ok) *xcd_ok = (ks == 1 || ks == 2 || ks == 4 || ks % 8 == 0) && (tiles * ks) % 8 == 0 && (ks >= 8 || tiles % (8 / ks) == 0);
+  return ks;
+}
+// Bytes of caller-owned workspace with which a split-K product of this shape runs DETERMINISTICALLY on this kernel: every (tile, slice)
+// work item leaves its f32 partial tile there by plain stores and pero_splitk_reduce_k adds the slices of a tile in slice order.  0: the
+// shape does not take this kernel or has one slice.  Without (enough) workspace the product falls back to f32 atomics.
+long long pero_gemm_e256_splitk_ws_bytes(long long M, long long N, long long K, int k_split) {
+  if (M % E_BM || N % E_BN || K % E_BK || K < 2 * E_BK) return 0;
+  const long long tiles = (M / E_BM) * (N / E_BN);
+  const int ks = e256_splitk_slices(tiles, K / E_BK, k_split, nullptr);
+  return ks > 1 ? tiles * ks * (long long)(E_BM * E_BN * sizeof(float)) : 0;
+}
+
+// Qualifies: one problem (batch 1), bf16 operands; stored bf16 output (alpha == 1) or a split-K f32 product; M % 256 == N % 256 == K % 64 == 0, K >= 128.
+// ws / ws_bytes: the caller's workspace for the split-K partial tiles (pero_gemm's `workspace`); never allocated here.
 int g_gemm_e_var = 0;
-bool pero_launch_gemm_e256(const GemmP& p0, long long batch, int k_split, bool ta, bool tb, bool out_f32, hipStream_t st, int var) {
+bool pero_launch_gemm_e256(const GemmP& p0, long long batch, int k_split, bool ta, bool tb, bool out_f32, hipStream_t st, int var, void* ws,
+                           long long ws_bytes) {
   if (p0.M % E_BM || p0.N % E_BN || p0.K % E_BK || p0.K < 2 * E_BK || batch != 1) return false;
   if (var < 0) var = g_gemm_e_var;
   const int wg_cap = ((var >> 8) & 0xff) * 8;  // diagnostic: at most this many workgroups (bits 8-15 of the variant, in units of 8)
@@ -776,26 +776,15 @@ bool pero_launch_gemm_e256(const GemmP& p0, long long batch, int k_split, bool t
     // split-K: f32 C, plain product, equal slices of whole K-tiles, one slice set per XCD
     if (!out_f32 || p0.bias || p0.resid || (p0.gate && !(var & (64 | 128))) || (p0.flags & ~(PERO_GEMM_ATOMIC | PERO_GEMM_TRANS_A | PERO_GEMM_TRANS_B | PERO_GEMM_TILE_V | PERO_GEMM_TILE256))) return false;
     const long long tiles = (p0.M / E_BM) * (p0.N / E_BN), steps = p0.K / E_BK;
-    ks = k_split;
-    if (ks <= 0) {  // the library chooses: one round of workgroups over the CUs
-      ks = (int)(256 / tiles);
-      if (ks >= 8) ks = (ks / 8) * 8; else if (ks >= 4) ks = 4; else if (ks >= 2) ks = 2; else ks = 1;
-    }
-    if (k_split <= 0) {
-      // an XCD-aligned slice count (one slice set per XCD: operand panels fetched once per L2) when it fills >= 90 % of the CUs
-      // that the plain count fills, else the plain count
-      int kx = (int)(256 / tiles);
-      kx = kx < 1 ? 1 : kx;
-      if (ks * tiles * 10 < kx * tiles * 9) ks = kx;
-    }
-    while (ks > 1 && steps / ks < 2) ks--;
-    const bool xcd_ok = (ks == 1 || ks == 2 || ks == 4 || ks % 8 == 0) && (tiles * ks) % 8 == 0 && (ks >= 8 || tiles % (8 / ks) == 0);
+    bool xcd_ok = false;
+    ks = e256_splitk_slices(tiles, steps, k_split, &xcd_ok);
     if (p0.lda >= (1LL << 22) || p0.ldb >= (1LL << 22)) return false;
     GemmP p = p0;
     p.kchunk = 0;
     dim3 grid((unsigned)(tiles * ks)), block(512);
     const int nsl = ks;
-    p.resid = (g_gemm_splitk_ws && !(var & (64 | 128)) && nsl > 1 && p0.ldc % 4 == 0 && (((size_t)p0.C) & 15) == 0) ? splitk_workspace(st, tiles * ks) : nullptr;
+    const bool ws_ok = ws && (((size_t)ws) & 15) == 0 && ws_bytes >= tiles * ks * (long long)(E_BM * E_BN * sizeof(float));
+    p.resid = (g_gemm_splitk_ws && ws_ok && !(var & (64 | 128)) && nsl > 1) ? ws : nullptr;
     auto reduce = [&]() {
       if (p.resid)
         hipLaunchKernelGGL(pero_splitk_reduce_k, dim3((unsigned)(tiles * 64)), dim3(256), 0, st, (const f4v*)p.resid, (float*)p.C, (long long)p.ldc,
@@ -803,26 +792,20 @@ bool pero_launch_gemm_e256(const GemmP& p0, long long batch, int k_split, bool t
     };
     if (!xcd_ok) {
       ks = -ks;
-      p.bias = (g_gemm_splitk_table && !(var & (64 | 128))) ? (const float*)splitk_item_table(st, (int)tiles, nsl) : nullptr;
+      p.kchunk = (g_gemm_splitk_table && !(var & (64 | 128))) ? 1 : 0;   // work items handed out XCD by XCD (esplitk_xcd_item)
     }
 #define LAUNCH_ES(TA_, TB_)                                                                                                \
   do {                                                                                                                     \
-    static bool attr_set = false;                                                                                          \
-    if (!attr_set) {                                                                                                       \
-      hipFuncSetAttribute((const void*)gemm_bf16_e256<TA_, TB_, EP_SPLITK, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, E_LDS_BYTES); \
-      attr_set = true;                                                                                                     \
-    }                                                                                                                      \
+    PERO_LDS_ATTR((gemm_bf16_e256<TA_, TB_, EP_SPLITK, 0>), E_LDS_BYTES);                                                  \
     hipLaunchKernelGGL((gemm_bf16_e256<TA_, TB_, EP_SPLITK, 0>), grid, block, E_LDS_BYTES, st, p, ks);                    \
   } while (0)
     if ((var & 128) && ta && tb) {
-      static bool attr128 = false;
-      if (!attr128) { hipFuncSetAttribute((const void*)gemm_bf16_e256<true, true, EP_SPLITK, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, E_LDS_BYTES); attr128 = true; }
+      PERO_LDS_ATTR((gemm_bf16_e256<true, true, EP_SPLITK, 128>), E_LDS_BYTES);
       hipLaunchKernelGGL((gemm_bf16_e256<true, true, EP_SPLITK, 128>), grid, block, E_LDS_BYTES, st, p, ks);
       return true;
     }
     if ((var & 64) && ta && tb) {
-      static bool attr64 = false;
-      if (!attr64) { hipFuncSetAttribute((const void*)gemm_bf16_e256<true, true, EP_SPLITK, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, E_LDS_BYTES); attr64 = true; }
+      PERO_LDS_ATTR((gemm_bf16_e256<true, true, EP_SPLITK, 64>), E_LDS_BYTES);
       hipLaunchKernelGGL((gemm_bf16_e256<true, true, EP_SPLITK, 64>), grid, block, E_LDS_BYTES, st, p, ks);
       return true;
     }
@@ -840,19 +823,20 @@ bool pero_launch_gemm_e256(const GemmP& p0, long long batch, int k_split, bool t
   if ((var & 128) && p0.resid && !relu && !bits && !rowdot && !cs) epi = EP_RESID;   // stamp build of the residual epilogue
   else if (var & (8 | 128)) epi = EP_PLAIN;          // stamp builds: `gate` is the stamp buffer
   else if (rowdot) { if (relu || bits || cs || p0.resid || !p0.gate || !p0.bias) return false; epi = EP_ROWDOT; }
-  else if (bits) { if (!p0.gate || p0.resid || (relu && cs)) return false; epi = relu ? EP_RELU_BITS : EP_GATE_BITS; }
+  else if (bits) {
+    if (!p0.gate || p0.resid || (relu && cs)) return false;
+    // the gate epilogue has no input-bias path (its `bias` is the column-sum OUTPUT under PERO_GEMM_COLSUM): a gated product WITH an
+    // input bias goes to gemm_bf16_r256, which adds it - both kernels then give the same bits at every tile count
+    if (!relu && p0.bias && !cs) return false;
+    epi = relu ? EP_RELU_BITS : EP_GATE_BITS;
+  }
   else if (cs || p0.gate) return false;              // column sums without the bit mask, bf16 gate rows: other kernels
   else if (p0.resid) { if (relu) return false; epi = EP_RESID; }
   else epi = relu ? EP_RELU : EP_PLAIN;
   if ((epi == EP_RESID && p0.ldr >= (1LL << 22)) || ((epi == EP_ROWDOT || bits) && p0.ldg >= (1LL << 22))) return false;
   if (epi != EP_PLAIN && (ta || tb)) return false;   // the fused epilogues exist for the K-contiguous products only
-  static int num_cus = 0;
-  if (!num_cus) {
-    hipDeviceProp_t prop; int dev = 0;
-    hipGetDevice(&dev); hipGetDeviceProperties(&prop, dev);
-    num_cus = prop.multiProcessorCount > 0 ? (prop.multiProcessorCount / 8) * 8 : 256;
-    if (num_cus < 8) num_cus = 8;
-  }
+  int num_cus = (pero_num_cus() / 8) * 8;
+  if (num_cus < 8) num_cus = 8;
   GemmP p = p0;
   p.kchunk = p.K;
   const long long nt = (p.M / E_BM) * (p.N / E_BN);
@@ -868,11 +852,7 @@ bool pero_launch_gemm_e256(const GemmP& p0, long long batch, int k_split, bool t
   }
 #define LAUNCH_E(TA_, TB_, EP_, VAR_)                                                                                            \
   do {                                                                                                                     \
-    static bool attr_set = false;                                                                                          \
-    if (!attr_set) {                                                                                                       \
-      hipFuncSetAttribute((const void*)gemm_bf16_e256<TA_, TB_, EP_, VAR_>, hipFuncAttributeMaxDynamicSharedMemorySize, E_LDS_BYTES); \
-      attr_set = true;                                                                                                     \
-    }                                                                                                                      \
+    PERO_LDS_ATTR((gemm_bf16_e256<TA_, TB_, EP_, VAR_>), E_LDS_BYTES);                                                     \
     hipLaunchKernelGGL((gemm_bf16_e256<TA_, TB_, EP_, VAR_>), grid, block, E_LDS_BYTES, st, p, ks);                                  \
   } while (0)
   if (!ta && !tb) {

@@ -260,11 +260,7 @@ bool pero_launch_gemm_o128(const GemmP& p0, long long batch, int k_split, bool t
   }
 #define LAUNCH_O(TA_, TB_, OF_)                                                                                           \
   do {                                                                                                                    \
-    static bool attr_set = false;                                                                                         \
-    if (!attr_set) {                                                                                                      \
-      hipFuncSetAttribute((const void*)gemm_bf16_o128<TA_, TB_, OF_>, hipFuncAttributeMaxDynamicSharedMemorySize, O_LDS_BYTES); \
-      attr_set = true;                                                                                                    \
-    }                                                                                                                     \
+    PERO_LDS_ATTR((gemm_bf16_o128<TA_, TB_, OF_>), O_LDS_BYTES);                                                          \
     hipLaunchKernelGGL((gemm_bf16_o128<TA_, TB_, OF_>), grid, block, O_LDS_BYTES, st, p, ks_xcd);                                 \
   } while (0)
   if (!ta && !tb) { if (out_f32) LAUNCH_O(false, false, true); else LAUNCH_O(false, false, false); }

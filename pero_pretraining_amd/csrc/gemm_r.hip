@@ -319,11 +319,7 @@ bool pero_launch_gemm_r256(const GemmP& p0, long long batch, int k_split, bool t
   }
 #define LAUNCH_R(TA_, TB_, OF_)                                                                                            \
   do {                                                                                                                     \
-    static bool attr_set = false;                                                                                          \
-    if (!attr_set) {                                                                                                       \
-      hipFuncSetAttribute((const void*)gemm_bf16_r256<TA_, TB_, OF_>, hipFuncAttributeMaxDynamicSharedMemorySize, R_LDS_BYTES); \
-      attr_set = true;                                                                                                     \
-    }                                                                                                                      \
+    PERO_LDS_ATTR((gemm_bf16_r256<TA_, TB_, OF_>), R_LDS_BYTES);                                                           \
     hipLaunchKernelGGL((gemm_bf16_r256<TA_, TB_, OF_>), grid, block, R_LDS_BYTES, st, p, ks_xcd);                                  \
   } while (0)
   if (!ta && !tb) { if (out_f32) LAUNCH_R(false, false, true); else LAUNCH_R(false, false, false); }

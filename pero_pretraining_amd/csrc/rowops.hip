@@ -491,11 +491,27 @@ __global__ __launch_bounds__(256) void ce_rows_k(const T* logits, const int64_t*
   if (tid == 0) { work[row] = lse - Elem<T>::ld(lr + lab); work[rows + 8 + row] = lse; }
 }
 // backward: dlogits[row] = (softmax(logits[row]) - onehot(label)) * weight(row) * dloss
+// With `index` (the compact form): block i writes row i of a (gridDim.x, V) matrix - the gradient row of logits row index[i] for
+// i < n_idx, a zero row behind (the padding up to whole GEMM tiles).  The head's two backward products then run over the selected
+// rows only: every other row of the dense dlogits is an exact zero.
 template <typename T>
 __global__ __launch_bounds__(256) void ce_bwd_k(const T* logits, const int64_t* labels, const int64_t* mask, float uw,
-                                                const float* dloss, const float* work, T* dlogits, long long rows, int V) {
+                                                const float* dloss, const float* work, T* dlogits, long long rows, int V,
+                                                const int64_t* index, long long n_idx) {
   const int tid = threadIdx.x;
-  const long long row = blockIdx.x;
+  long long row = blockIdx.x;
+  if (index) {
+    const bool pad = (long long)blockIdx.x >= n_idx;
+    const long long src = pad ? 0 : index[blockIdx.x];
+    const long long lab0 = pad ? 0 : labels[src], mk0 = pad ? -1 : mask[src];
+    if (pad || !((mk0 == 1) || (mk0 == 0 && lab0 >= 0 && uw >= 0.f))) {   // padding row / a listed row that takes no part: zeros
+      T* o = dlogits + (long long)blockIdx.x * V;
+      for (int c = tid; c < V; c += 256) Elem<T>::st(o + c, 0.f);
+      return;
+    }
+    dlogits += ((long long)blockIdx.x - src) * V;   // row `src` of the arithmetic below lands in output row blockIdx.x
+    row = src;
+  }
   {
   const long long lab = labels[row];
   const long long mk = mask[row];
@@ -603,10 +619,24 @@ extern "C" int pero_masked_ce_bwd(const void* logits, const int64_t* labels, con
     pero_set_error("pero_masked_ce_bwd: zero fill failed");
     return PERO_E_LAUNCH;
   }
-  if (dtype == PERO_F32) hipLaunchKernelGGL((ce_bwd_k<float>), dim3((unsigned)rows), dim3(256), 0, st, (const float*)logits, labels, mask, unmasked_weight, dloss, work, (float*)dlogits, (long long)rows, (int)V);
-  else if (dtype == PERO_BF16) hipLaunchKernelGGL((ce_bwd_k<bf16raw>), dim3((unsigned)rows), dim3(256), 0, st, (const bf16raw*)logits, labels, mask, unmasked_weight, dloss, work, (bf16raw*)dlogits, (long long)rows, (int)V);
+  if (dtype == PERO_F32) hipLaunchKernelGGL((ce_bwd_k<float>), dim3((unsigned)rows), dim3(256), 0, st, (const float*)logits, labels, mask, unmasked_weight, dloss, work, (float*)dlogits, (long long)rows, (int)V, (const int64_t*)nullptr, 0LL);
+  else if (dtype == PERO_BF16) hipLaunchKernelGGL((ce_bwd_k<bf16raw>), dim3((unsigned)rows), dim3(256), 0, st, (const bf16raw*)logits, labels, mask, unmasked_weight, dloss, work, (bf16raw*)dlogits, (long long)rows, (int)V, (const int64_t*)nullptr, 0LL);
   else PERO_REQUIRE(false, "pero_masked_ce_bwd: bad dtype");
   PERO_CHECK_LAUNCH("pero_masked_ce_bwd");
+  return PERO_OK;
+}
+extern "C" int pero_masked_ce_bwd_rows(const void* logits, const int64_t* labels, const int64_t* mask, float unmasked_weight,
+                                       const float* dloss, const float* work, const int64_t* index, int64_t n_idx, int64_t n_rows_out,
+                                       void* dlogits_rows, int64_t rows, int64_t V, int dtype, void* stream) {
+  PERO_REQUIRE(logits && labels && mask && work && dlogits_rows && (index || n_idx == 0), "pero_masked_ce_bwd_rows: null pointer");
+  PERO_REQUIRE(rows > 0 && V > 0 && n_idx >= 0 && n_idx <= n_rows_out && n_rows_out > 0 && n_rows_out < 2147483647LL, "pero_masked_ce_bwd_rows: bad sizes");
+  hipStream_t st = (hipStream_t)stream;
+  // (index == null with n_idx == 0: every output row is padding; the kernel needs a non-null pointer to take the compact form)
+  const int64_t* ix = index ? index : labels;
+  if (dtype == PERO_F32) hipLaunchKernelGGL((ce_bwd_k<float>), dim3((unsigned)n_rows_out), dim3(256), 0, st, (const float*)logits, labels, mask, unmasked_weight, dloss, work, (float*)dlogits_rows, (long long)rows, (int)V, ix, (long long)n_idx);
+  else if (dtype == PERO_BF16) hipLaunchKernelGGL((ce_bwd_k<bf16raw>), dim3((unsigned)n_rows_out), dim3(256), 0, st, (const bf16raw*)logits, labels, mask, unmasked_weight, dloss, work, (bf16raw*)dlogits_rows, (long long)rows, (int)V, ix, (long long)n_idx);
+  else PERO_REQUIRE(false, "pero_masked_ce_bwd_rows: bad dtype");
+  PERO_CHECK_LAUNCH("pero_masked_ce_bwd_rows");
   return PERO_OK;
 }
 

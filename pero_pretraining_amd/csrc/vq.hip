@@ -217,8 +217,7 @@ extern "C" int pero_vq_argmin(const float* x, const float* codebook, int64_t* in
   hipLaunchKernelGGL(sqnorm_k, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, x, sx, (long long)M, (int)D);
   hipLaunchKernelGGL(sqnorm_k, dim3((unsigned)((K + 3) / 4)), dim3(256), 0, st, codebook, se, (long long)K, (int)D);
   if (M % VF_BX == 0 && K % VF_BC == 0 && D % VF_BK == 0 && aligned16(x) && aligned16(codebook)) {
-    static bool attr = false;
-    if (!attr) { hipFuncSetAttribute((const void*)vq_argmin_fast_k, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * VF_STAGE); attr = true; }
+    PERO_LDS_ATTR(vq_argmin_fast_k, 2 * VF_STAGE);
     hipLaunchKernelGGL(vq_argmin_fast_k, dim3((unsigned)(M / VF_BX)), dim3(256), 2 * VF_STAGE, st, x, codebook, sx, se, indices, best_dist,
                        (int)K, (int)D);
   } else {

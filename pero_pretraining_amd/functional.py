@@ -4,10 +4,13 @@ Token layout: every activation is a row-major (N*S, d) matrix of token rows (lin
 what the reference reaches after its `n d s -> s n d` / `s n d -> n d s` transposes
 (models/transformers.py:82-89) - those are pure layout and vanish here.
 
-Attention (round 1): per (line, head) batched GEMMs on the packed qkv tensor + a row softmax kernel
-(scores kept in f32), i.e. the unfused form of torch SDPA.  Every product of the backward pass is the
-same GEMM kernel with a different operand-layout flag; weight gradients are accumulated straight into
-the parameters' `.grad` buffers with f32 atomics (split-K over the token dimension).
+Attention: bf16 with head_dim 128 and S % 128 == 0 runs the fused flash-style kernels of csrc/attention.hip on the
+packed qkv tensor (scores never stored; one f32 log-sum-exp per query saved for the backward); f32 parity mode and other
+shapes take the unfused form of torch SDPA - per (line, head) batched GEMMs + a row softmax kernel, scores in f32.
+Every product of the backward pass is pero_gemm with a different operand-layout flag: input gradients as K-contiguous
+products on transposed bf16 weight copies, weight gradients as split-K products into the parameters' f32 `.grad`
+buffers - partial tiles summed in slice order through a caller-owned workspace (ops.gemm_workspace; run-to-run
+reproducible), f32 atomics only for short reductions.
 """
 import math
 

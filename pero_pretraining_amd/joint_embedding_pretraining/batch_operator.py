@@ -29,7 +29,8 @@ class BatchOperator:
         if not (isinstance(value, torch.Tensor) and value.is_cuda):
             # the losses select rows by these masks: with the host original at hand they build their index lists without a
             # device sync (losses.host_mask)
-            t._pero_host = value.numpy() if isinstance(value, torch.Tensor) else np.asarray(value)
+            # a PRIVATE copy (N x S bytes): the caller's array may be a staging buffer that is rewritten two batches later
+            t._pero_host = np.array(value.numpy() if isinstance(value, torch.Tensor) else value, copy=True)
         return t
 
     @staticmethod

@@ -17,16 +17,7 @@ def _rows(t, dtype):
     return t2
 
 
-def host_mask(m):
-    """The mask's values on the HOST when they are known there without a device sync: numpy arrays, CPU tensors, and device
-    tensors that the batch operator / collator uploaded from host arrays (they carry the original as `_pero_host`)."""
-    if isinstance(m, np.ndarray):
-        return m
-    if isinstance(m, torch.Tensor):
-        if not m.is_cuda:
-            return m.numpy()
-        return getattr(m, "_pero_host", None)
-    return np.asarray(m)
+host_mask = ops.host_mask
 
 
 def _nz(mask, device, value=1):

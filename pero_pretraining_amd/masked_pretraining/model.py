@@ -110,6 +110,59 @@ class _GatherTokensFn(torch.autograd.Function):
         return dx, None, None
 
 
+def masked_row_list(mask, rows=None):
+    """Flat positions with mask == 1 as an int64 list - WITHOUT a device sync, or None when that is impossible.  The list is known
+    on the host when the caller hands it over (`rows`), or when the mask is a host array / a device tensor that carries its host
+    original (the reference's BatchOperator draws the mask in numpy: batch_operator.py:27-32).  A mask that exists on the device
+    only would cost a torch.nonzero round trip per step: callers fall back to their dense path instead."""
+    if rows is not None:
+        return rows.reshape(-1)
+    h = ops.host_mask(mask)
+    if h is None:
+        return None
+    return torch.from_numpy(np.flatnonzero(np.asarray(h).reshape(-1) == 1).astype(np.int64))
+
+
+class _HeadCEFn(torch.autograd.Function):
+    """LinearHead + MaskedCrossEntropyLoss of a TRAINING step as one autograd node (masked_pretraining/model.py:60-61,78-82).
+    Forward: exactly the two calls of the separate path - logits of EVERY position (the result dict carries them, like the
+    reference's) and the masked mean CE.  Backward: with unmasked_weight None the dense dlogits has an exact zero row for every
+    position outside the mask (~85 %), so the head's weight-gradient and input-gradient products, the bias gradient and the CE
+    gradient itself run on the listed masked rows alone (gathered into whole 256-row tiles) and the token gradient is scattered
+    into a zero matrix: same values (the dropped terms are products with exact zeros), no 2 GB zero fill, no column-sum pass over
+    it.  The returned logits are marked non-differentiable: the loss is the step's only differentiable output."""
+
+    @staticmethod
+    def forward(ctx, tokens, weight, bias, labels, mask, index, dtype):
+        x2 = tokens.detach().reshape(-1, tokens.shape[-1])
+        if x2.dtype != dtype or not x2.is_contiguous():
+            x2 = x2.to(dtype).contiguous()
+        logits = F.linear_fwd(x2, weight, bias, dtype)
+        lab = labels.reshape(-1).to(device=x2.device, dtype=torch.int64).contiguous()
+        msk = mask.reshape(-1).to(device=x2.device, dtype=torch.int64).contiguous()
+        loss, work = ops.masked_ce_fwd(logits, lab, msk, None)
+        ctx.save_for_backward(x2, logits, lab, msk, work, index)
+        ctx.weight, ctx.bias, ctx.dtype, ctx.shape = weight, bias, dtype, tokens.shape
+        ctx.mark_non_differentiable(logits)
+        return logits, loss[0]
+
+    @staticmethod
+    def backward(ctx, _dlogits, dloss):
+        x2, logits, lab, msk, work, index = ctx.saved_tensors
+        n = index.numel()
+        n_pad = ((n + 255) // 256) * 256                                   # whole 256-row GEMM tiles; pad rows are zero
+        dl = dloss.detach().reshape(1).to(torch.float32)                   # stays on the device: no host sync
+        dlog = ops.masked_ce_bwd_rows(logits, lab, msk, work, index, n_pad, dloss=dl)
+        xm = ops.gather_rows(x2, index, n_rows_out=n_pad)
+        dxm = F.linear_bwd(dlog, xm, ctx.weight, ctx.bias, ctx.dtype, need_dx=ctx.needs_input_grad[0])
+        dx = None
+        if dxm is not None:
+            dx = torch.zeros_like(x2)
+            ops.scatter_add_rows(dxm, index, dx)                            # reads the first n rows of dxm
+            dx = dx.view(ctx.shape)
+        return dx, None, None, None, None, None, None
+
+
 class MaskedCrossEntropyLoss(torch.nn.Module):
     """masked_pretraining/model.py:72-95."""
 
@@ -131,6 +184,11 @@ class MaskedTransformerEncoder(torch.nn.Module):
     # their backward run on those rows alone (about 15 % of them: SURVEY.md section 8 a8/a9) - same loss and gradients,
     # result["output"] is None and result["output_rows"] / result["rows"] hold the logits of the masked positions.
     head_rows = "all"
+    # "masked" (default): in those same training steps with head_rows == "all" the head's BACKWARD runs on the masked rows only
+    # (_HeadCEFn; forward, result["output"] and every value unchanged).  "dense": backward over all positions through the separate
+    # head / loss nodes (result["output"] then stays differentiable).  Needs the mask's row list without a device sync
+    # (masked_row_list); otherwise the dense path runs.
+    head_backward = "masked"
 
     def __init__(self, backbone, head, loss=None):
         super().__init__()
@@ -139,12 +197,9 @@ class MaskedTransformerEncoder(torch.nn.Module):
         self.loss = MaskedCrossEntropyLoss() if loss is None else loss
 
     def _forward_masked_rows(self, x, labels, mask, rows=None):
-        if rows is not None:  # flat positions with mask == 1, listed by the caller (int64): no host sync for the count
-            index = rows.reshape(-1)
-        elif isinstance(mask, torch.Tensor):
-            index = torch.nonzero(mask.reshape(-1) == 1, as_tuple=False).reshape(-1)  # one host sync (row count)
-        else:  # the reference's BatchOperator hands the mask over as a host array: the count costs nothing
-            index = torch.from_numpy(np.flatnonzero(np.asarray(mask).reshape(-1) == 1))
+        index = masked_row_list(mask, rows)   # caller's list, or from the mask's host original: never a device sync
+        if index is None:
+            return None  # a device-only mask: the dense path (a torch.nonzero round trip per step would cost more than it saves)
         n = index.numel()
         if n == 0:
             return None  # the dense path reproduces the reference's NaN for an empty selection
@@ -168,6 +223,19 @@ class MaskedTransformerEncoder(torch.nn.Module):
                 return result
         elif self.head_rows not in ("all", "masked"):
             raise ValueError(f"Unknown head_rows: {self.head_rows}")
+        if self.head_backward not in ("masked", "dense"):
+            raise ValueError(f"Unknown head_backward: {self.head_backward}")
+        if self.head_backward == "masked" and self.training and torch.is_grad_enabled() and labels is not None and mask is not None \
+                and type(self.loss) is MaskedCrossEntropyLoss and self.loss.unmasked_weight is None and isinstance(self.head, LinearHead):
+            index = masked_row_list(mask, rows)
+            if index is not None and index.numel() > 0:
+                n = x.shape[0]
+                tokens = self.backbone.encode_tokens(x, mask)
+                if not isinstance(mask, torch.Tensor):
+                    mask = torch.from_numpy(np.asarray(mask))
+                logits, loss = _HeadCEFn.apply(tokens, self.head.linear.weight, self.head.linear.bias, torch.as_tensor(labels), mask,
+                                               index.to(tokens.device, non_blocking=True), compute_dtype())
+                return {"output": logits.view(n, -1, logits.shape[-1]), "loss": loss}
         output = self.encode(x, mask)
         if mask is not None and not isinstance(mask, torch.Tensor):
             mask = torch.from_numpy(mask).to(output.device)

@@ -1,5 +1,8 @@
 """Tensor-level wrappers over the C ABI (libpero_hip.so).  PyTorch supplies device memory and the
 current HIP stream; all arithmetic happens in the hand-written kernels.  No CPU fallback."""
+import threading
+
+import numpy as np
 import torch
 
 from . import _lib
@@ -34,6 +37,30 @@ def _req_cuda(*ts):
 # optional launch timeline for bench.py's roofline leg: list of (start_event, end_event, flops, kernel tag)
 gemm_timeline = None
 
+# Split-K workspaces (partial tiles of the weight-gradient products, pero_gemm's `workspace`): the C ABI never allocates, so the
+# caller - this module - keeps one buffer per (device, stream) from PyTorch's caching allocator, grown on demand.  Products on one
+# stream run one after the other and may share it; the weight-gradient side stream and the autograd threads' streams get their own.
+_ws_lock = threading.Lock()
+_ws_cache = {}
+
+
+def gemm_workspace(nbytes, device):
+    """uint8 device buffer of at least `nbytes` for the current stream (None for 0)."""
+    if nbytes <= 0:
+        return None
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
+    with _ws_lock:
+        buf = _ws_cache.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = _ws_cache[key] = torch.empty(max(int(nbytes), 64 << 20), device=device, dtype=torch.uint8)
+    return buf
+
+
+def release_workspaces():
+    """Drop the cached split-K workspaces (they return to PyTorch's allocator once the queued work has run)."""
+    with _ws_lock:
+        _ws_cache.clear()
+
 
 def gemm_raw(A, B, C, M, N, K, lda, ldb, ldc, *, bias=None, residual=None, gate=None, ldr=0, ldg=0, batch=1,
              batch_inner=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), alpha=1.0, flags=0, k_split=1, in_dtype=None,
@@ -41,12 +68,17 @@ def gemm_raw(A, B, C, M, N, K, lda, ldb, ldc, *, bias=None, residual=None, gate=
     """Direct pero_gemm call; A/B/C may be tensors (pointer taken at storage offset) or raw ints."""
     _req_cuda(A, B, C)
     idt = dt(A) if in_dtype is None else in_dtype
+    odt = dt(C) if out_dtype is None else out_dtype
+    ws = None
+    if flags & GEMM_ATOMIC:
+        need = _lib.lib().pero_gemm_workspace_bytes(M, N, K, batch, int(flags), int(k_split), idt, odt)
+        ws = gemm_workspace(need, A.device if isinstance(A, torch.Tensor) else torch.device("cuda", torch.cuda.current_device()))
     if gemm_timeline is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     call("pero_gemm", ptr(A), ptr(B), ptr(C), ptr(bias), ptr(residual), ptr(gate), M, N, K, lda, ldb, ldc, ldr, ldg,
          batch, batch_inner, sA[0], sA[1], sB[0], sB[1], sC[0], sC[1], float(alpha), int(flags), int(k_split),
-         idt, dt(C) if out_dtype is None else out_dtype, stream())
+         idt, odt, ptr(ws), ws.numel() if ws is not None else 0, stream())
     if gemm_timeline is not None:
         e1.record()
         fast = idt == PERO_BF16 and M % 128 == 0 and N % 128 == 0 and K % 64 == 0 and not (flags & GEMM_FORCE_GENERIC)
@@ -168,6 +200,28 @@ def masked_ce_bwd(logits, labels, mask, work, unmasked_weight=None, dloss=None):
     call("pero_masked_ce_bwd", ptr(logits), ptr(labels), ptr(mask), -1.0 if unmasked_weight is None else float(unmasked_weight),
          ptr(dloss), ptr(work), ptr(dlogits), rows, V, dt(logits), stream())
     return dlogits
+
+
+def masked_ce_bwd_rows(logits, labels, mask, work, index, n_rows_out, unmasked_weight=None, dloss=None):
+    """Compact CE gradient: (n_rows_out, V), row i = gradient row of logits row index[i], zero rows behind index.numel()."""
+    rows, V = logits.shape
+    out = torch.empty((n_rows_out, V), device=logits.device, dtype=logits.dtype)
+    call("pero_masked_ce_bwd_rows", ptr(logits), ptr(labels), ptr(mask), -1.0 if unmasked_weight is None else float(unmasked_weight),
+         ptr(dloss), ptr(work), ptr(index), index.numel(), n_rows_out, ptr(out), rows, V, dt(logits), stream())
+    return out
+
+
+def host_mask(m):
+    """The mask's values on the HOST when they are known there without a device sync: numpy arrays, CPU tensors, and device
+    tensors that a batch operator / collator / prefetcher uploaded from host arrays (they carry a private copy of the original as
+    `_pero_host`; such a device mask must not be modified in place after the upload).  None: the mask lives on the device only."""
+    if isinstance(m, np.ndarray):
+        return m
+    if isinstance(m, torch.Tensor):
+        if not m.is_cuda:
+            return m.numpy()
+        return getattr(m, "_pero_host", None)
+    return np.asarray(m)
 
 
 def colsum(x, out):

@@ -27,8 +27,91 @@ def test_library_exports_every_header_symbol():
     assert len(names) >= 20
     for n in names:
         assert hasattr(h, n), f"{n} declared in include/pero_hip.h but not exported"
-    assert set(_lib.SIGNATURES) | {"pero_last_error", "pero_abi_version", "pero_set_option"} == set(names)
-    assert h.pero_abi_version() == 1
+    assert set(_lib.SIGNATURES) | {"pero_last_error", "pero_abi_version", "pero_set_option", "pero_gemm_workspace_bytes"} == set(names)
+    assert h.pero_abi_version() == _lib.ABI_VERSION == 2
+
+
+def test_library_never_allocates():
+    """include/pero_hip.h: the caller owns every buffer.  No allocation, free, blocking copy or device synchronisation anywhere in csrc/."""
+    import glob
+    import re
+    csrc = os.path.join(ROOT, "pero_pretraining_amd", "csrc")
+    banned = re.compile(r"\b(hipMalloc\w*|hipFree\w*|hipMemcpy(?!Async)\w*|hipDeviceSynchronize|hipStreamSynchronize|hipHostMalloc|hipMallocAsync)\s*\(")
+    for f in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.hpp"))):
+        for i, line in enumerate(open(f), 1):
+            code = line.split("//")[0]
+            assert not banned.search(code), f"{f}:{i}: {line.strip()}"
+
+
+def test_gemm_workspace_query_needs_no_gpu():
+    """pero_gemm_workspace_bytes depends on the shape only: split-K weight gradients of long reductions on 256x256 tiles get
+    tiles x slices x 256 KiB, everything else 0."""
+    from pero_pretraining_amd import _lib
+    h = _lib.lib()
+    A = _lib.GEMM_ATOMIC | _lib.GEMM_TRANS_A | _lib.GEMM_TRANS_B
+    # linear1's weight gradient at 1024 lines: 2048 x 512 outputs = 16 tiles, 16 slices
+    assert h.pero_gemm_workspace_bytes(2048, 512, 262144, 1, A, 0, _lib.PERO_BF16, _lib.PERO_F32) == 16 * 16 * 256 * 256 * 4
+    # in_proj's: 1536 x 512 = 12 tiles, 21 slices (not XCD-aligned)
+    assert h.pero_gemm_workspace_bytes(1536, 512, 262144, 1, A, 0, _lib.PERO_BF16, _lib.PERO_F32) == 12 * 21 * 256 * 256 * 4
+    assert h.pero_gemm_workspace_bytes(1536, 512, 262144, 1, A, 4, _lib.PERO_BF16, _lib.PERO_F32) == 12 * 4 * 256 * 256 * 4
+    for args in [(2048, 512, 262144, 1, A & ~_lib.GEMM_ATOMIC, 1, _lib.PERO_BF16, _lib.PERO_BF16),   # stored product
+                 (2048, 512, 4096, 1, A, 0, _lib.PERO_BF16, _lib.PERO_F32),                          # short reduction: 128x128 kernel, atomics
+                 (2048, 500, 262144, 1, A, 0, _lib.PERO_BF16, _lib.PERO_F32),                        # ragged
+                 (2048, 512, 262144, 2, A, 0, _lib.PERO_BF16, _lib.PERO_F32),                        # batched
+                 (2048, 512, 262144, 1, A, 0, _lib.PERO_F32, _lib.PERO_F32)]:                        # parity mode
+        assert h.pero_gemm_workspace_bytes(*args) == 0, args
+    # a workspace size without a pointer is rejected before any launch
+    rc = h.pero_gemm(1, 1, 1, None, None, None, 256, 256, 256, 256, 256, 256, 0, 0, 1, 1, 0, 0, 0, 0, 0, 0, 1.0, 0, 1, 1, 1, None, 64, None)
+    assert rc == -1 and b"workspace" in h.pero_last_error()
+
+
+@pytest.mark.gpu
+def test_splitk_from_two_threads_on_two_streams_is_bit_identical():
+    """The C ABI is re-entrant: the split-K weight-gradient path called concurrently from two Python threads, each on its own stream
+    with its own caller-owned workspace, gives bit-identical results - to each other, to a single-threaded call and from run to run
+    (forward runs on the main thread, weight gradients on autograd worker threads: include/pero_hip.h conventions)."""
+    import threading
+    from pero_pretraining_amd import ops
+    torch.manual_seed(0)
+    dev = torch.device("cuda")
+    K, M, N = 65536, 1536, 512     # 12 tiles x 21 slices: the unaligned slice count (work items XCD by XCD) and a long reduction
+    a = torch.randn(K, M, device=dev).bfloat16()
+    b = torch.randn(K, N, device=dev).bfloat16()
+    from pero_pretraining_amd import _lib
+    need = _lib.lib().pero_gemm_workspace_bytes(M, N, K, 1, _lib.GEMM_ATOMIC | _lib.GEMM_TRANS_A | _lib.GEMM_TRANS_B, 0, _lib.PERO_BF16, _lib.PERO_F32)
+    assert need == 12 * 21 * 256 * 256 * 4
+    ref = torch.zeros(M, N, device=dev)
+    ops.gemm(a, b, ref, trans_a=True, trans_b=True, atomic=True, k_split=0)
+    torch.cuda.synchronize()
+    exact = a.float().T @ b.float()
+    assert float((ref - exact).abs().max()) < 2e-3 * float(exact.abs().max())
+    outs, errs = [None, None], []
+
+    def worker(i):
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                res = []
+                for _ in range(6):
+                    c = torch.zeros(M, N, device=dev)
+                    ops.gemm(a, b, c, trans_a=True, trans_b=True, atomic=True, k_split=0)
+                    res.append(c)
+                st.synchronize()
+            outs[i] = res
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ths = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errs, errs
+    for res in outs:
+        for c in res:
+            assert torch.equal(c, ref)
+    # two distinct workspaces were handed out (one per stream), none by the library
+    assert len({v.data_ptr() for v in ops._ws_cache.values()}) >= 2
 
 
 def test_argument_validation_without_gpu():

@@ -192,8 +192,12 @@ def test_head_on_masked_rows_only_gives_the_same_step(golden):
     bb = M.init_backbone({"type": "vit", "num_blocks": 2, "model_dim": 128, "num_heads": 1, "feedforward_dim": 256})
     hd = M.init_head({"type": "linear", "in_features": 128, "out_features": 4096})
     dense = M.MaskedTransformerEncoder(bb, hd).cuda().train()
+    dense.head_backward = "dense"          # separate head / loss nodes, backward over every position
     sparse = copy.deepcopy(dense)
     sparse.head_rows = "masked"
+    hybrid = copy.deepcopy(dense)          # the default: head forward on every position, head BACKWARD on the masked rows (_HeadCEFn)
+    hybrid.head_backward = "masked"
+    assert M.MaskedTransformerEncoder.head_backward == "masked" and M.MaskedTransformerEncoder.head_rows == "all"
     rng = np.random.default_rng(5)
     images = torch.from_numpy(rng.integers(0, 256, (5, 40, 256, 3), dtype=np.uint8)).cuda()
     labels = rng.integers(0, 4096, (5, 32)).astype(np.int64)
@@ -201,15 +205,32 @@ def test_head_on_masked_rows_only_gives_the_same_step(golden):
     mask = ((rng.random((5, 32)) < 0.2) & (labels >= 0)).astype(np.int64)
     offs = rng.integers(0, 4096 - 32, 5)
     res = {}
-    for name, model, m in (("dense", dense, mask), ("sparse", sparse, mask), ("sparse_dev", sparse, torch.from_numpy(mask).cuda())):
+    row_list = torch.from_numpy(np.flatnonzero(mask.reshape(-1) == 1)).cuda()
+    dev_mask = torch.from_numpy(mask).cuda()                     # exists on the device only: its row list needs a sync ...
+    tagged = torch.from_numpy(mask).cuda()
+    tagged._pero_host = mask.copy()                              # ... unless it carries its host original (BatchOperator / DevicePrefetcher)
+    for name, model, m, rows in (("dense", dense, mask, None), ("sparse", sparse, mask, None), ("sparse_rows", sparse, dev_mask, row_list),
+                                 ("sparse_tagged", sparse, tagged, None), ("sparse_dev", sparse, dev_mask, None),
+                                 ("hybrid", hybrid, mask, None), ("hybrid_tagged", hybrid, tagged, None), ("hybrid_dev", hybrid, dev_mask, None)):
         model.zero_grad()
         model.backbone.set_offsets(offs)
-        out = model(images, torch.from_numpy(labels).cuda(), m)
+        out = model(images, torch.from_numpy(labels).cuda(), m) if rows is None else model(images, torch.from_numpy(labels).cuda(), m, rows=rows)
         out["loss"].backward()
         torch.cuda.synchronize()
         res[name] = (float(out["loss"]), {k: p.grad.detach().clone() for k, p in model.named_parameters()}, out)
     n = int(mask.sum())
-    for name in ("sparse", "sparse_dev"):
+    # head backward on the masked rows: logits of every position bit for bit, the same loss, the same gradients
+    for name in ("hybrid", "hybrid_tagged", "hybrid_dev", "sparse_dev"):
+        out = res[name][2]
+        assert torch.equal(out["output"], res["dense"][2]["output"]), name
+        assert res[name][0] == res["dense"][0], name
+        if name in ("hybrid", "hybrid_tagged"):
+            assert not out["output"].requires_grad        # _HeadCEFn ran (its logits are not differentiable) ...
+        else:
+            assert out["output"].requires_grad            # ... a device-only mask takes the dense path: no device sync for the count
+        for k, g in res["dense"][1].items():
+            assert (res[name][1][k] - g).abs().max() <= 1e-5 * max(float(g.abs().max()), 1e-6), (name, k)
+    for name in ("sparse", "sparse_rows", "sparse_tagged"):
         out = res[name][2]
         assert out["output"] is None and out["output_rows"].shape == (n, 4096) and out["rows"].numel() == n
         assert abs(res[name][0] - res["dense"][0]) <= 1e-6 * abs(res["dense"][0])

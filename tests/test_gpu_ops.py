@@ -350,6 +350,16 @@ def test_masked_ce(ops, dtype, uw):
     assert rel_err(dl, lr.grad) < (1e-5 if dtype == torch.float32 else 2 ** -7)
     dl2 = ops.masked_ce_bwd(dev(logits), dev(labels), dev(mask), work, uw, dloss=torch.full((1,), 0.5, device="cuda"))
     assert rel_err(dl2, 0.5 * lr.grad) < (1e-5 if dtype == torch.float32 else 2 ** -7)
+    # compact form (pero_masked_ce_bwd_rows): the listed rows bit for bit, zero padding rows behind; a listed row that takes no
+    # part in the loss is a zero row
+    sel = torch.nonzero(mask == 1).reshape(-1)
+    extra = torch.nonzero((mask == 0) & (labels < 0)).reshape(-1)[:2]          # take no part under either setting
+    index = torch.cat([sel, extra])
+    n_out = ((index.numel() + 15) // 16) * 16 + 16
+    rows_c = ops.masked_ce_bwd_rows(dev(logits), dev(labels), dev(mask), work, dev(index), n_out, uw)
+    assert rows_c.shape == (n_out, V)
+    assert torch.equal(rows_c[:sel.numel()], dl[dev(sel)])
+    assert float(rows_c[sel.numel():].float().abs().max()) == 0.0
 
 
 def test_masked_ce_empty_mask_is_nan(ops):
@@ -470,7 +480,8 @@ def test_vq_argmin_codebook_8192(ops, golden):
     w.normal_()
     flat = np.ascontiguousarray(g["cb8192.features"].transpose(0, 2, 3, 1)).reshape(-1, 512)
     idx, best = ops.vq_argmin(dev(flat), dev(w), want_dist=True)
-    near_tie = (g["cb8192.second"] - g["cb8192.best"]) < 1e-4 * np.abs(g["cb8192.best"])
+    # (round 1 exempted relative margins below 1e-4; the kernel reproduces the reference's decisions down to 1e-6 - g17 pins 2e-6)
+    near_tie = (g["cb8192.second"] - g["cb8192.best"]) < 1e-6 * np.abs(g["cb8192.best"])
     got = idx.cpu().numpy()
     assert np.array_equal(got[~near_tie], g["cb8192.indices"][~near_tie])
     assert (got != g["cb8192.indices"]).sum() <= near_tie.sum()

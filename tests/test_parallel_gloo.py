@@ -159,3 +159,35 @@ def _seed_worker(rank, world, port):
 
 def test_global_mean_backward_seed_world2():
     mp.spawn(_seed_worker, args=(2, _free_port()), nprocs=2, join=True)
+
+
+def test_bench_self_launch_relays_one_json_line_world2():
+    """`python bench.py --gpus 2` with no RANK in the environment starts the two ranks itself (a torch.distributed.run child; the
+    parent never touches a GPU) and relays rank 0's ONE JSON line: rehearsed on CPU over gloo with the GPU work replaced by a
+    trivial step (--plumbing-test): rank environment, process group, barrier-bracketed max-over-ranks timing, descriptor juggling."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--plumbing-test", "--steps", "4", "--warmup", "1",
+                        "--repeats", "2"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=240)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["warmup"] == 1 and d["repeats"] == 2
+    assert d["distributed"] == {"world_size": 2, "backend": "gloo", "self_launched": True}
+    assert d["all_reduce_check"] == 2.0
+    assert d["ms_per_step"] >= 2.0          # the slowest rank (2 ms sleep per step) sets the time: max over ranks
+    # --spawn: the same path with one rank
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--spawn", "--plumbing-test", "--steps", "2", "--warmup", "0",
+                        "--repeats", "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=240)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    d = json.loads(r.stdout.decode().strip())
+    assert d["distributed"] == {"world_size": 1, "backend": "gloo", "self_launched": True}
+    # a mismatch between --gpus and the launcher's world size is an error, not a silent single-rank run
+    env2 = dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--plumbing-test"], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, env=env2, timeout=120)
+    assert r.returncode != 0 and b"WORLD_SIZE" in r.stderr

@@ -60,6 +60,32 @@ __global__ __launch_bounds__(512) void kg(unsigned char* C, long long pitch, int
   if (lane == 0)
     for (int i = 0; i < 17; i++) out[(blockIdx.x * 8 + wave) * 17 + i] = st[i] - st[0];
 }
+// lane order of a conflict-free lane transpose: lanes 0-31 = (row L >> 1, piece L & 1), lanes 32-63 = (row (L - 32) >> 1, piece 2 + (L & 1)):
+// adjacent PAIRS of lanes cover 32 contiguous bytes, the wave-instruction still 16 rows x 64 B.  MODE 1: quads (reference), 0: pairs
+template <int MODE>
+__global__ __launch_bounds__(512) void k2(unsigned char* C, long long pitch, int reps, int nw, unsigned long long* out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const u4v v = {(unsigned)lane, (unsigned)wave, 3u, 4u};
+  unsigned long long st[17];
+  const int row = MODE ? (lane >> 2) : ((lane & 31) >> 1), piece = MODE ? (lane & 3) : (2 * (lane >> 5) + (lane & 1));
+  for (int r = 0; r < reps; r++) {
+    unsigned char* tile = C + ((long long)blockIdx.x * reps + r) * 256 * pitch;
+    unsigned char* base = tile + (long long)((wave >> 2) * 128 + row) * pitch + (wave & 3) * 128 + piece * 16;
+    __syncthreads();
+    if (wave < nw) {
+      st[0] = __builtin_amdgcn_s_memtime();
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        *(u4v*)(base + (long long)(i >> 1) * 16 * pitch + (i & 1) * 64) = v;
+        st[i + 1] = __builtin_amdgcn_s_memtime();
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+  }
+  if (lane == 0)
+    for (int i = 0; i < 17; i++) out[(blockIdx.x * 8 + wave) * 17 + i] = st[i] - st[0];
+}
 int main() {
   const int G = 8, reps = 4;
   unsigned char* C; hipMalloc(&C, (size_t)G * reps * 4096 * 8192);
@@ -88,5 +114,15 @@ int main() {
     printf("\n");                                                                                           \
   } while (0)
   RUNG(0, 8); RUNG(1, 8); RUNG(2, 8); RUNG(0, 1); RUNG(1, 1);
+#define RUN2(M_, nw_)                                                                                     \
+  do {                                                                                                      \
+    for (int it = 0; it < 2; it++) hipLaunchKernelGGL(k2<M_>, dim3(G), dim3(512), 0, 0, C, 4096LL, reps, nw_, out); \
+    hipDeviceSynchronize();                                                                                 \
+    hipMemcpy(h.data(), out, h.size() * 8, hipMemcpyDeviceToHost);                                          \
+    printf("transposed layout, %s, %d storing waves: wave 0 store 16 issued at %5llu, last wave at %5llu; wave 0 steps:", M_ ? "quads (64 B)" : "pairs (32 B) per half", nw_, h[16], h[(nw_ - 1) * 17 + 16]); \
+    for (int i = 1; i <= 16; i++) printf(" %llu", h[i] - h[i - 1]);                                         \
+    printf("\n");                                                                                           \
+  } while (0)
+  RUN2(1, 8); RUN2(0, 8); RUN2(1, 1); RUN2(0, 1);
   return 0;
 }
