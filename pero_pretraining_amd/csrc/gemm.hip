@@ -367,6 +367,8 @@ __global__ __launch_bounds__(256) void gemm_generic(GemmP p) {
 //   forcing one family for A/B runs and tests: 1 = 128x128x64 persistent, 4 = o128, 7 = r256, 20 = e256 (any tile count).
 extern int g_gemm_e_var;
 extern int g_attn_bwd_pair;           // attention.hip
+extern int g_attn_pipe;
+extern int g_attn_lh;
 extern int g_gemm_splitk_ws;          // gemm_e.hip
 extern int g_gemm_splitk_table;
 static int g_gemm_policy = 0;         // 0 = auto, 1 = 128x128x64 persistent kernel (this file), 4 = gemm_bf16_o128, 7 = gemm_bf16_r256, 20 = gemm_bf16_e256
@@ -379,6 +381,8 @@ extern "C" int pero_set_option(const char* name, int value) {
   if (name && !strcmp(name, "gemm_policy")) { g_gemm_policy = value; return PERO_OK; }
   if (name && !strcmp(name, "gemm_e_var")) { g_gemm_e_var = value; return PERO_OK; }
   if (name && !strcmp(name, "attn_bwd_pair")) { g_attn_bwd_pair = value; return PERO_OK; }
+  if (name && !strcmp(name, "attn_pipe")) { g_attn_pipe = value; return PERO_OK; }
+  if (name && !strcmp(name, "attn_lh")) { g_attn_lh = value; return PERO_OK; }
   if (name && !strcmp(name, "splitk_workspace")) { g_gemm_splitk_ws = value; return PERO_OK; }
   if (name && !strcmp(name, "splitk_table")) { g_gemm_splitk_table = value; return PERO_OK; }
   if (name && !strcmp(name, "gemm_e256_min")) { g_gemm_e256_min = value; return PERO_OK; }

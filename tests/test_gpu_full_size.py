@@ -133,25 +133,35 @@ def test_bench_scale_step_equals_the_weighted_sum_of_its_sub_batches(B, relu_bit
     sub = 16
     images = torch.from_numpy(rng.integers(0, 256, (B, 40, 2048, 3), dtype=np.uint8)).cuda()
     labels = torch.from_numpy(rng.integers(0, 4096, (B, 256))).cuda()
-    mask = torch.from_numpy((rng.random((B, 256)) < 0.15).astype(np.int64)).cuda()
+    mask_h = (rng.random((B, 256)) < 0.15).astype(np.int64)
+    mask = torch.from_numpy(mask_h).cuda()
     offs = rng.integers(0, 4096 - 256, B)
 
-    def step(sl):
+    def step(sl, m=None):
+        # default: the mask as the reference's BatchOperator hands it over - a host array - so that the head's backward runs on the
+        # masked rows only (_HeadCEFn: the default training path, what bench.py times)
         model.zero_grad()
         model.backbone.set_offsets(offs[sl])
         with P.autocast(True):
-            res = model(images[sl], labels[sl], mask[sl])
+            res = model(images[sl], labels[sl], mask_h[sl] if m is None else m)
         res["loss"].backward()
         return res["output"].detach(), float(res["loss"]), {k: p.grad.detach().float().clone() for k, p in model.named_parameters()}
 
     out_full, loss_full, g_full = step(slice(0, B))
     n_full = int(mask.sum())
-    # the optional head-on-masked-rows path at this size: the same loss and gradients as the all-positions step
+    # the dense head backward (a device-only mask: no row list without a sync) at this size: identical logits and loss, the same
+    # gradients up to the order of the f32 sums
+    out_d, loss_d, g_d = step(slice(0, B), mask)
+    assert torch.equal(out_d, out_full) and loss_d == loss_full
+    for k in g_full:
+        rel = float((g_d[k] - g_full[k]).norm() / g_full[k].norm().clamp_min(1e-12))
+        assert rel <= 2e-3, (k, rel)
+    # the optional head-on-masked-rows FORWARD at this size: the same loss and gradients as the all-positions step
     model.head_rows = "masked"
     model.zero_grad()
     model.backbone.set_offsets(offs)
     with P.autocast(True):
-        res = model(images, labels, mask)
+        res = model(images, labels, mask_h)
     res["loss"].backward()
     model.head_rows = "all"
     assert res["output"] is None and abs(float(res["loss"]) - loss_full) <= 1e-5 * abs(loss_full)

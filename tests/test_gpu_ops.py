@@ -273,6 +273,41 @@ def test_fused_attention_fwd_bwd(ops, n, s, h):
         assert rel_err(got_pair[:, sl], gref[:, sl]) < 3e-2, name
 
 
+@pytest.mark.parametrize("n", [1, 3, 70])
+def test_attention_backward_variants_give_the_same_bits(ops, n):
+    """S = 256, D handed in, bias gradient wanted: the paired kernels with software-pipelined operand reads (default), their
+    compiler-scheduled form (attn_pipe 0) and the persistent one-(line, head)-per-pass kernel (attn_lh 1; 70 lines x 4 heads = more
+    units than CUs: the workgroups loop) must agree bit for bit in dqkv; the bias gradient up to the order of its f32 sums."""
+    from pero_pretraining_amd._lib import call
+    s, h, hd = 256, 4, 128
+    d = h * hd
+    g = torch.Generator().manual_seed(40 + n)
+    qkv = dev((torch.randn(n * s, 3 * d, generator=g) * 0.7).bfloat16())
+    dout = dev(torch.randn(n * s, d, generator=g).bfloat16())
+    out, lse = ops.attention_fwd_fused(qkv, n, s, h)
+    dvec = (out.float() * dout.float()).reshape(n * s, h, hd).sum(-1).contiguous()
+    res = {}
+    try:
+        for name, pipe, lh in (("pipelined", 1, 0), ("compiler", 0, 0), ("line_head", 1, 1)):
+            call("pero_set_option", b"attn_pipe", pipe)
+            call("pero_set_option", b"attn_lh", lh)
+            db = torch.zeros(3 * d, device="cuda")
+            res[name] = (ops.attention_bwd_fused(qkv, None, dout, lse, n, s, h, dbias=db, dvec=dvec), db)
+            o2, l2 = ops.attention_fwd_fused(qkv, n, s, h)
+            assert torch.equal(o2, out) and torch.equal(l2, lse)
+    finally:
+        call("pero_set_option", b"attn_pipe", 1)
+        call("pero_set_option", b"attn_lh", 0)
+    ref, dbr = res["pipelined"]
+    assert bool(torch.isfinite(ref.float()).all())
+    for name in ("compiler", "line_head"):
+        got, db = res[name]
+        assert torch.equal(got, ref), name
+        assert float((db - dbr).abs().max()) <= 1e-5 * max(1.0, float(dbr.abs().max())), name
+    want = ref.float().sum(0)
+    assert float((dbr - want).abs().max()) <= 1e-3 * max(1.0, float(want.abs().max()))
+
+
 # ------------------------------------------------------------------------------------------ row kernels
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("rows,d", [(37, 64), (64, 256), (130, 512)])

@@ -13,7 +13,7 @@ def stats(path, steps, out):
     with open(out, "w") as f:
         f.write(f"# rocprofv3 --kernel-trace --stats summary ({path.split('/')[-1]}), {steps} profiled steps\n\n")
         f.write("| kernel | calls/step | avg us | ms/step | % |\n|---|---|---|---|---|\n")
-        for r in rows[:30]:
+        for r in rows[:40]:
             f.write(f"| `{r['Name'][:90]}` | {int(r['Calls']) / steps:.1f} | {float(r['AverageNs']) / 1e3:.1f} | "
                     f"{float(r['TotalDurationNs']) / steps / 1e6:.3f} | {float(r['Percentage']):.1f} |\n")
         f.write(f"\ntotal kernel time per step: {tot / steps / 1e6:.3f} ms\n")
