@@ -250,6 +250,18 @@ int pero_rownorm_bwd(const void* xn, const void* dxn, const float* inv, const fl
  * dim 0), loss_out[0] = mean_l line_loss[l]; dsim (dtype, may be null) = d loss_out / d sim */
 int pero_ntxent_cols(const float* sim, float* line_loss, float* loss_out, void* dsim, int64_t lines, int64_t S, int dtype,
                      void* stream);
+/* Cross-rank negatives (NTXentLoss(cross_rank_negatives=True): the data-parallel extension named by BASELINE.json's north_star; the
+ * reference's loss is per line and has no such term).  cross (lines*S, L) f32: similarities of every view-2 row with the L pooled
+ * embeddings of all ranks' lines (pooled embedding own0 + l belongs to line l itself and is left out).  Column j of line l is
+ * normalised over its S own rows AND those L - 1 negatives in one log-sum-exp:
+ *   line_loss[l] = mean_j ( log( sum_i exp(sim[l][i][j]) + sum_{l' != own0 + l} exp(cross[l*S + j][l']) ) - sim[l][j][j] ),
+ * loss_out[0] = mean_l line_loss[l]; dsim (dtype, lines x S x S) and dcross (dtype, lines*S x L), may be null = d loss_out / d input. */
+int pero_ntxent_cols_cross(const float* sim, const float* cross, float* line_loss, float* loss_out, void* dsim, void* dcross,
+                           int64_t lines, int64_t S, int64_t L, int64_t own0, int dtype, void* stream);
+/* out[l][c] (f32) = mean over the S rows of line l of x[l*S + s][c] (the pooled embedding of a line); d % 8 == 0 */
+int pero_line_mean(const void* x, float* out, int64_t lines, int64_t S, int64_t d, int dtype, void* stream);
+/* dst[l*S + s][c] += scale * src[l][c] for every row s of line l (the backward of pero_line_mean: scale = 1 / S); dst dtype, src f32 */
+int pero_add_line_rows(void* dst, const float* src, int64_t lines, int64_t S, int64_t d, float scale, int dtype, void* stream);
 
 /* ---- evaluation -------------------------------------------------------------
  * replaces masked_pretraining/tester.py:72-113 (_update_errors / _topk / _calculate_errors: host numpy argmax and

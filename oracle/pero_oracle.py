@@ -321,6 +321,26 @@ def ntxent_loss(x, y, image_masks1, image_masks2, shift_masks1, shift_masks2, te
     return {"loss": torch.stack(losses).mean()}
 
 
+def vqvae_quantize(features, sd):
+    """VQVAE.quantize (reference models/autoencoders.py:142-146) in eval mode: 1x1 encoder projection (a matmul over the channel axis,
+    Conv2d semantics autoencoders.py:113), VectorQuantizer.forward (autoencoders.py:204-241: expanded squared distance, first argmin,
+    straight-through output), 1x1 decoder projection (autoencoders.py:114).  features (N, C, 1, T) f32, sd: the layer's tensors under the
+    reference's names.  Returns (projected rows (N*T, D), labels (N*T,), projected tokens (N, C_dec, 1, T))."""
+    x = torch.as_tensor(features, dtype=torch.float32)
+    n, c, _, t = x.shape
+    we = torch.as_tensor(sd["encoder_projection_layer.weight"]).reshape(-1, c)
+    be = torch.as_tensor(sd["encoder_projection_layer.bias"])
+    rows = x.permute(0, 2, 3, 1).reshape(-1, c) @ we.t() + be
+    e = torch.as_tensor(sd["vq.embedding.weight"])
+    dist = (rows ** 2).sum(dim=1, keepdim=True) + (e ** 2).sum(dim=1) - 2 * rows @ e.t()
+    labels = torch.argmin(dist, dim=1)
+    q = rows + (e[labels] - rows)
+    wd = torch.as_tensor(sd["decoder_projection_layer.weight"]).reshape(-1, e.shape[1])
+    bd = torch.as_tensor(sd["decoder_projection_layer.bias"])
+    tok = (q @ wd.t() + bd).reshape(n, 1, t, -1).permute(0, 3, 1, 2)
+    return rows, labels, tok
+
+
 def ntxent_cross_loss(x, y, lines_per_rank, temperature=0.1):
     """The cross-rank-negatives EXTENSION of NT-Xent (no reference counterpart; pero_pretraining_amd NTXentLoss(cross_rank_negatives=
     True)) restated on the CONCATENATED batch x, y (L, S, D) of all ranks: per line the reference's column-normalised softmax

@@ -59,6 +59,9 @@ SIGNATURES = {
     "pero_rownorm_fwd": [_vp, _vp, _vp, _i64, _i64, _i32, _vp],
     "pero_rownorm_bwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp],
     "pero_ntxent_cols": [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp],
+    "pero_ntxent_cols_cross": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp],
+    "pero_line_mean": [_vp, _vp, _i64, _i64, _i64, _i32, _vp],
+    "pero_add_line_rows": [_vp, _vp, _i64, _i64, _i64, _f32, _i32, _vp],
     "pero_vq_ema_update": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _f64, _f64, _vp],
     "pero_rowdot_blocks": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp],
     "pero_label_rank": [_vp, _i64, _vp, _vp, _i64, _i64, _vp, _i32, _vp, _vp, _i32, _vp],

@@ -93,6 +93,14 @@ class BatchCreator:
             cs = torch.tensor(crop_shifts, dtype=torch.int32).to(self.device, non_blocking=True)
         im1, im2, sm1, sm2, shifts_t = ops.line_masks(w1, l1, target_width // sub, sub, w2, l2, cs)
         shifts = [c + (a - b) for c, a, b in zip(crop_shifts, left1, left2)] if paired else None   # dataloader.py:126
+        # The widths and paddings behind these masks are host values: the same few hundred bytes per line are also written on the
+        # host and travel with the device masks (`_pero_host`), so that the losses and the masked head list their rows without a
+        # device sync (ops.host_mask) - a device-only mask costs a torch.nonzero round trip per mask and step
+        host = self._host_masks([l.shape[1] for l in lines1], left1, [l.shape[1] for l in lines2] if paired else None, left2,
+                                crop_shifts, target_width // sub, sub)
+        for t, h in zip((im1, im2, sm1, sm2), host):
+            if t is not None:
+                t._pero_host = h
 
         original_images1 = self._stack_originals(data, "image_original", H, C)
         original_images2 = self._stack_originals(data, "image2_original", H, C)
@@ -127,6 +135,27 @@ class BatchCreator:
     def calculate_padded_image_width(self, image_width: int):
         """dataloader.py:197-198."""
         return int(np.ceil(image_width / self.padding_coefficient) * self.padding_coefficient) + self.padding_coefficient
+
+    @staticmethod
+    def _host_masks(widths1, left1, widths2, left2, crop_shifts, S, sub):
+        """The masks of pero_line_masks (csrc/collate.hip; the reference's dataloader.py:92-96, 124-138) on the host: image masks,
+        three-valued shift masks (1 shared, 2 shared-but-padding, 0 not shared).  Returns (im1, im2, sm1, sm2), uint8 (B, S)."""
+        pos = np.arange(S)[None, :]
+        a1 = np.asarray(left1, dtype=np.int64)[:, None]
+        e1 = a1 + (np.asarray(widths1, dtype=np.int64)[:, None] + sub - 1) // sub
+        im1 = ((pos >= a1) & (pos < e1)).astype(np.uint8)
+        if widths2 is None:
+            return im1, None, None, None
+        a2 = np.asarray(left2, dtype=np.int64)[:, None]
+        e2 = a2 + (np.asarray(widths2, dtype=np.int64)[:, None] + sub - 1) // sub
+        im2 = ((pos >= a2) & (pos < e2)).astype(np.uint8)
+        shift = np.asarray(crop_shifts, dtype=np.int64)[:, None] + a1 - a2
+        on1 = np.where(shift < 0, pos < S + shift, pos >= shift)
+        rev = S - 1 - pos                                          # shift_mask2 = reverse(shift_mask1)
+        on2 = np.where(shift < 0, rev < S + shift, rev >= shift)
+        sm1 = np.where(on1, np.where(im1 == 1, 1, 2), 0).astype(np.uint8)
+        sm2 = np.where(on2, np.where(im2 == 1, 1, 2), 0).astype(np.uint8)
+        return im1, im2, sm1, sm2
 
     # ---- device side ---------------------------------------------------------------------------------------------
     def _draw_left_padding(self, line_image, target_width):

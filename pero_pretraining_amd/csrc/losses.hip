@@ -259,6 +259,105 @@ __global__ __launch_bounds__(256) void ntxent_cols_k(const float* sim, float* li
   if (threadIdx.x == 0) line_loss[blockIdx.x] = ((sm[0] + sm[1]) + (sm[2] + sm[3])) / (float)S;
 }
 
+
+// ---- cross-rank NT-Xent (NTXentLoss(cross_rank_negatives=True); no reference counterpart) -------------------------------------------
+// pooled[l][c] = mean over the S rows of line l of x[(l*S + s)][c]   (f32 out; x in T)
+template <typename T>
+__global__ __launch_bounds__(256) void line_mean_k(const T* x, float* out, int S, int d) {
+  const long long l = blockIdx.y;
+  const int c = (blockIdx.x * 256 + threadIdx.x) * 8;
+  if (c >= d) return;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const T* p = x + l * S * (long long)d + c;
+  for (int s = 0; s < S; s++) {
+    float v[8];
+    load8<T>(p + (long long)s * d, v);
+#pragma unroll
+    for (int e = 0; e < 8; e++) acc[e] += v[e];
+  }
+  const float w = 1.0f / (float)S;
+#pragma unroll
+  for (int e = 0; e < 8; e++) acc[e] *= w;
+  store8<float>(out + l * d + c, acc);
+}
+// dst[(l*S + s)][c] += scale * src[l][c]   (the backward of the mean: every row of a line receives the line's gradient / S)
+template <typename T>
+__global__ __launch_bounds__(256) void add_line_rows_k(T* dst, const float* src, int S, int d, float scale) {
+  const long long l = blockIdx.y;
+  const int c = (blockIdx.x * 256 + threadIdx.x) * 8;
+  if (c >= d) return;
+  float g[8];
+  load8<float>(src + l * d + c, g);
+  T* p = dst + l * S * (long long)d + c;
+  for (int s = 0; s < S; s++) {
+    float v[8];
+    load8<T>(p + (long long)s * d, v);
+#pragma unroll
+    for (int e = 0; e < 8; e++) v[e] += scale * g[e];
+    store8<T>(p + (long long)s * d, v);
+  }
+}
+// One workgroup per line.  Column j of the line's similarity block (sim[l][i][j], i = 0..S-1) and row l*S + j of `cross` (the
+// similarities of y_j with the L pooled embeddings; the line's own, index own0 + l, is left out) share ONE log-sum-exp:
+//   lse_j = log( sum_i exp(sim[i][j]) + sum_{l' != own} exp(cross[j][l']) ),   line_loss = mean_j (lse_j - sim[j][j]),
+//   dsim[i][j] = (exp(sim[i][j] - lse_j) - [i == j]) w,   dcross[j][l'] = exp(cross[j][l'] - lse_j) w (0 for the own line),  w = 1 / (S lines).
+// Pass 1: thread j walks column j of sim (coalesced over the threads); pass 2: a wave per row of cross, lanes over l' (coalesced);
+// the statistics meet in LDS.  Nothing is concatenated, masked or copied (torch did: cat, one_hot, masked_fill, logsumexp).
+template <typename T>
+__global__ __launch_bounds__(256) void ntxent_cols_cross_k(const float* sim, const float* cross, float* line_loss, T* dsim, T* dcross, int S, int L,
+                                                           int lines, int own0) {
+  extern __shared__ float sh[];          // [S] max, [S] sum, [S] lse
+  float* cmx = sh; float* csum = sh + S; float* clse = sh + 2 * S;
+  __shared__ float red[4];
+  const long long l = blockIdx.x;
+  const float* s = sim + l * S * (long long)S;
+  const float* cr = cross + l * S * (long long)L;
+  const int own = own0 + (int)l;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int j = tid; j < S; j += 256) {
+    float mx = -INFINITY;
+    for (int r = 0; r < S; r++) mx = fmaxf(mx, s[(long long)r * S + j]);
+    float sum = 0.f;
+    for (int r = 0; r < S; r++) sum += expf(s[(long long)r * S + j] - mx);
+    cmx[j] = mx; csum[j] = sum;
+  }
+  __syncthreads();
+  for (int j = wave; j < S; j += 4) {
+    const float* row = cr + (long long)j * L;
+    float mx = -INFINITY;
+    for (int c = lane; c < L; c += 64) if (c != own) mx = fmaxf(mx, row[c]);
+    mx = wave_max(mx);
+    const float m1 = cmx[j], m = fmaxf(m1, mx);
+    float sum = 0.f;
+    for (int c = lane; c < L; c += 64) if (c != own) sum += expf(row[c] - m);
+    sum = wave_sum(sum);
+    if (lane == 0) clse[j] = logf(csum[j] * expf(m1 - m) + sum) + m;
+  }
+  __syncthreads();
+  const float w = 1.0f / ((float)S * (float)lines);
+  float acc = 0.f;
+  for (int j = tid; j < S; j += 256) {
+    const float lse = clse[j];
+    acc += lse - s[(long long)j * S + j];
+    if (dsim) {
+      T* o = dsim + l * S * (long long)S;
+      for (int r = 0; r < S; r++) Elem<T>::st(o + (long long)r * S + j, (expf(s[(long long)r * S + j] - lse) - (r == j ? 1.f : 0.f)) * w);
+    }
+  }
+  if (dcross) {
+    for (int j = wave; j < S; j += 4) {
+      const float* row = cr + (long long)j * L;
+      T* o = dcross + (l * S + j) * (long long)L;
+      const float lse = clse[j];
+      for (int c = lane; c < L; c += 64) Elem<T>::st(o + c, c == own ? 0.f : expf(row[c] - lse) * w);
+    }
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) red[wave] = acc;
+  __syncthreads();
+  if (tid == 0) line_loss[l] = ((red[0] + red[1]) + (red[2] + red[3])) / (float)S;
+}
+
 #define DISPATCH_T(dtype, NAME, ...)                                                              \
   do {                                                                                            \
     if (dtype == PERO_F32) { NAME(float, __VA_ARGS__); }                                          \
@@ -380,5 +479,39 @@ extern "C" int pero_ntxent_cols(const float* sim, float* line_loss, float* loss_
 #undef L_
   hipLaunchKernelGGL(sum_scale_k, dim3(1), dim3(256), 0, st, line_loss, loss_out, (long long)lines, 1.0f / (float)lines);
   PERO_CHECK_LAUNCH("pero_ntxent_cols");
+  return PERO_OK;
+}
+
+extern "C" int pero_line_mean(const void* x, float* out, int64_t lines, int64_t S, int64_t d, int dtype, void* stream) {
+  PERO_REQUIRE(x && out && lines > 0 && S > 0 && d > 0 && d % 8 == 0 && lines < 65536, "pero_line_mean: bad arguments (d %% 8 == 0)");
+  PERO_REQUIRE(v8_ok(d, dtype, {x}) && aligned16(out), "pero_line_mean: 16-byte aligned rows");
+  dim3 grid((unsigned)((d / 8 + 255) / 256), (unsigned)lines), block(256);
+#define L_(T, ...) hipLaunchKernelGGL((line_mean_k<T>), grid, block, 0, (hipStream_t)stream, (const T*)x, out, (int)S, (int)d)
+  DISPATCH_T(dtype, L_, 0);
+#undef L_
+  PERO_CHECK_LAUNCH("pero_line_mean");
+  return PERO_OK;
+}
+extern "C" int pero_add_line_rows(void* dst, const float* src, int64_t lines, int64_t S, int64_t d, float scale, int dtype, void* stream) {
+  PERO_REQUIRE(dst && src && lines > 0 && S > 0 && d > 0 && d % 8 == 0 && lines < 65536, "pero_add_line_rows: bad arguments (d %% 8 == 0)");
+  PERO_REQUIRE(v8_ok(d, dtype, {dst}) && aligned16(src), "pero_add_line_rows: 16-byte aligned rows");
+  dim3 grid((unsigned)((d / 8 + 255) / 256), (unsigned)lines), block(256);
+#define L_(T, ...) hipLaunchKernelGGL((add_line_rows_k<T>), grid, block, 0, (hipStream_t)stream, (T*)dst, src, (int)S, (int)d, scale)
+  DISPATCH_T(dtype, L_, 0);
+#undef L_
+  PERO_CHECK_LAUNCH("pero_add_line_rows");
+  return PERO_OK;
+}
+extern "C" int pero_ntxent_cols_cross(const float* sim, const float* cross, float* line_loss, float* loss_out, void* dsim, void* dcross,
+                                      int64_t lines, int64_t S, int64_t L, int64_t own0, int dtype, void* stream) {
+  PERO_REQUIRE(sim && cross && line_loss && loss_out && lines > 0 && S > 0 && L > 0 && own0 >= 0 && own0 + lines <= L && S <= 4096,
+               "pero_ntxent_cols_cross: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+#define L_(T, ...) hipLaunchKernelGGL((ntxent_cols_cross_k<T>), dim3((unsigned)lines), dim3(256), (size_t)(3 * S * sizeof(float)), st, sim, cross, line_loss, \
+                                      (T*)dsim, (T*)dcross, (int)S, (int)L, (int)lines, (int)own0)
+  DISPATCH_T(dtype, L_, 0);
+#undef L_
+  hipLaunchKernelGGL(sum_scale_k, dim3(1), dim3(256), 0, st, line_loss, loss_out, (long long)lines, 1.0f / (float)lines);
+  PERO_CHECK_LAUNCH("pero_ntxent_cols_cross");
   return PERO_OK;
 }

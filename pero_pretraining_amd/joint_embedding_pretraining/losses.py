@@ -169,67 +169,79 @@ class _NTXentFn(torch.autograd.Function):
         return dx.view(n, s, D), dy.view(n, s, D), None, None
 
 
-class _BmmNT(torch.autograd.Function):
-    """per line: out[l] = a[l] @ b[l]^T * alpha   (N, S, D) x (N, T, D) -> (N, S, T) f32, on batched pero_gemm"""
+def _is_nccl(group):
+    try:
+        return dist.get_backend(group) == "nccl"
+    except Exception:  # noqa: BLE001
+        return False
+
+
+class _NTXentCrossFn(torch.autograd.Function):
+    """NT-Xent with cross-rank negatives as ONE autograd node on HIP kernels (no torch elementwise / cat / logsumexp kernels, no host
+    sync): row normalisation (pero_rownorm_*), the per-line pooled embedding (pero_line_mean / pero_add_line_rows), the two similarity
+    products and their backward (pero_gemm), the joint column log-sum-exp over [own rows | gathered negatives] and its gradients
+    (pero_ntxent_cols_cross).  The only exchange: the pooled embeddings, all-gathered forward (world x N x D f32), their gradients
+    reduce-scattered back to the owning rank in the backward (RCCL: reduce_scatter_tensor into a fresh tensor; gloo: all-reduce of a
+    private copy).  The upstream gradient is applied once, at the end (it is the same scalar on every rank of a data-parallel step)."""
 
     @staticmethod
-    def forward(ctx, a, b, alpha):
-        n, s, D = a.shape
-        t = b.shape[1]
-        out = torch.empty((n, s, t), device=a.device, dtype=torch.float32)
-        ops.gemm_raw(a, b, out, s, t, D, D, D, t, batch=n, sA=(s * D, 0), sB=(t * D, 0), sC=(s * t, 0), alpha=alpha)
-        ctx.save_for_backward(a, b)
-        ctx.alpha = alpha
-        return out
+    def forward(ctx, x, y, temperature, dtype, group):
+        n, s, D = x.shape
+        T = float(temperature)
+        xn, invx = ops.rownorm_fwd(_rows(x, dtype))
+        yn, invy = ops.rownorm_fwd(_rows(y, dtype))
+        pm = ops.line_mean(xn, n, s)                                   # (N, D) f32: mean of the normalised view-1 rows of a line
+        p, invp = ops.rownorm_fwd(pm)                                  # one bounded negative per line
+        world, rank = 1, 0
+        gathered = p
+        if group is not None:
+            world, rank = dist.get_world_size(group), dist.get_rank(group)
+            gathered = torch.empty((world * n, D), device=p.device, dtype=p.dtype)
+            if _is_nccl(group):
+                dist.all_gather_into_tensor(gathered, p, group=group)
+            else:
+                parts = list(gathered.view(world, n, D).unbind(0))
+                dist.all_gather(parts, p, group=group)
+        L = gathered.shape[0]
+        if dtype == torch.bfloat16:
+            glp = ops.cast_to_bf16(gathered, torch.empty((L, D), device=p.device, dtype=torch.bfloat16))
+        else:
+            glp = gathered
+        sim = torch.empty((n, s, s), device=x.device, dtype=torch.float32)
+        ops.gemm_raw(xn, yn, sim, s, s, D, D, D, s, batch=n, sA=(s * D, 0), sB=(s * D, 0), sC=(s * s, 0), alpha=1.0 / T)
+        cross = ops.gemm(yn, glp, alpha=1.0 / T, out_dtype=torch.float32)          # (N*S, L): y_j . p_l' / T
+        loss, _, dsim, dcross = ops.ntxent_cols_cross(sim, cross, rank * n, dtype)
+        ctx.save_for_backward(xn, yn, invx, invy, dsim, dcross, p, invp, glp)
+        ctx.meta = (n, s, D, T, group, world, rank)
+        return loss[0]
 
     @staticmethod
     def backward(ctx, g):
-        a, b = ctx.saved_tensors
-        n, s, D = a.shape
-        t = b.shape[1]
-        gd = g.contiguous().to(a.dtype)
-        da, db = torch.empty_like(a), torch.empty_like(b)
-        ops.gemm_raw(gd, b, da, s, D, t, t, D, D, batch=n, sA=(s * t, 0), sB=(t * D, 0), sC=(s * D, 0), alpha=ctx.alpha, flags=GEMM_TRANS_B)
-        ops.gemm_raw(gd, a, db, t, D, s, t, D, D, batch=n, sA=(s * t, 0), sB=(s * D, 0), sC=(t * D, 0), alpha=ctx.alpha,
+        xn, yn, invx, invy, dsim, dcross, p, invp, glp = ctx.saved_tensors
+        n, s, D, T, group, world, rank = ctx.meta
+        gdev = g.detach().reshape(1).to(torch.float32)
+        dxn = torch.empty_like(xn)
+        dyn = torch.empty_like(yn)
+        ops.gemm_raw(dsim, yn, dxn, s, D, s, s, D, D, batch=n, sA=(s * s, 0), sB=(s * D, 0), sC=(s * D, 0), alpha=1.0 / T, flags=GEMM_TRANS_B)
+        ops.gemm_raw(dsim, xn, dyn, s, D, s, s, D, D, batch=n, sA=(s * s, 0), sB=(s * D, 0), sC=(s * D, 0), alpha=1.0 / T,
                      flags=GEMM_TRANS_A | GEMM_TRANS_B)
-        return da, db, None
-
-
-class _MmNT(torch.autograd.Function):
-    """out = a @ b^T * alpha   (M, D) x (L, D) -> (M, L) f32, on pero_gemm"""
-
-    @staticmethod
-    def forward(ctx, a, b, alpha):
-        out = ops.gemm(a, b, alpha=alpha, out_dtype=torch.float32)
-        ctx.save_for_backward(a, b)
-        ctx.alpha = alpha
-        return out
-
-    @staticmethod
-    def backward(ctx, g):
-        a, b = ctx.saved_tensors
-        gd = g.contiguous().to(a.dtype)
-        da = ops.gemm(gd, b, trans_b=True, alpha=ctx.alpha)                  # (M, L) x (L, D)
-        db = ops.gemm(gd, a, trans_a=True, trans_b=True, alpha=ctx.alpha)    # (L, M) x (M, D)
-        return da, db, None
-
-
-class _AllGatherRows(torch.autograd.Function):
-    """all-gather of equally shaped row blocks over the ranks; backward: every rank's gradient block summed back to its owner"""
-
-    @staticmethod
-    def forward(ctx, t, group):
-        ctx.group, ctx.world, ctx.rank = group, dist.get_world_size(group), dist.get_rank(group)
-        parts = [torch.empty_like(t) for _ in range(ctx.world)]
-        dist.all_gather(parts, t.contiguous(), group=group)
-        return torch.cat(parts, dim=0)
-
-    @staticmethod
-    def backward(ctx, g):
-        g = g.contiguous()
-        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=ctx.group)   # (reduce-scatter semantics; all-reduce keeps gloo and RCCL on one path)
-        n = g.shape[0] // ctx.world
-        return g[ctx.rank * n:(ctx.rank + 1) * n].clone(), None
+        # through the negatives: d yn += dcross @ P / T ;  d P = dcross^T @ yn / T  (f32: it is summed over the ranks)
+        dyn = ops.gemm(dcross, glp, trans_b=True, alpha=1.0 / T, residual=dyn)
+        dgath = ops.gemm(dcross, yn, trans_a=True, trans_b=True, alpha=1.0 / T, out_dtype=torch.float32)      # (L, D)
+        if group is not None:
+            if _is_nccl(group):
+                dp = torch.empty((n, D), device=dgath.device, dtype=torch.float32)
+                dist.reduce_scatter_tensor(dp, dgath, op=dist.ReduceOp.SUM, group=group)
+            else:
+                dist.all_reduce(dgath, op=dist.ReduceOp.SUM, group=group)      # (dgath is this function's own tensor)
+                dp = dgath[rank * n:(rank + 1) * n].contiguous()
+        else:
+            dp = dgath
+        dpm = ops.rownorm_bwd(p, dp, invp)                              # through p = normalize(pm)
+        ops.add_line_rows_(dxn, dpm, n, s, 1.0 / s)                     # through pm = mean over the line's rows of xn
+        dx = ops.rownorm_bwd(xn, dxn, invx, gdev)
+        dy = ops.rownorm_bwd(yn, dyn, invy, gdev)
+        return dx.view(n, s, D), dy.view(n, s, D), None, None, None
 
 
 class NTXentLoss(torch.nn.Module):
@@ -245,8 +257,7 @@ class NTXentLoss(torch.nn.Module):
         loss_line = mean_j [ log( sum_i exp(x_i . y_j / T) + sum_{lines l' != line, all ranks} exp(p_l' . y_j / T) ) - x_j . y_j / T ].
     Gradients flow back through the gathered rows to the rank that owns them (sum over ranks), so the data-parallel average of
     the parameter gradients is the gradient of the mean loss over the global batch.  The restatement on the concatenated batch is
-    oracle/pero_oracle.py::ntxent_cross_loss; the heavy products run on pero_gemm, the exponentials on torch elementwise kernels
-    (an extension outside the reference-parity path)."""
+    oracle/pero_oracle.py::ntxent_cross_loss; everything runs on HIP kernels (_NTXentCrossFn)."""
 
     def __init__(self, temperature=0.1, cross_rank_negatives=False, process_group=None):
         super().__init__()
@@ -267,22 +278,7 @@ class NTXentLoss(torch.nn.Module):
         return {"loss": self._cross(x, y)}
 
     def _cross(self, x, y):
-        dtype, T = compute_dtype(), float(self.temperature)
-        n, s, D = x.shape
         group = None
         if dist.is_available() and dist.is_initialized():
             group = self.process_group if self.process_group is not None else dist.group.WORLD
-        xn = torch.nn.functional.normalize(x.float(), dim=-1, eps=1e-12)
-        yn = torch.nn.functional.normalize(y.float(), dim=-1, eps=1e-12)
-        pooled = torch.nn.functional.normalize(xn.mean(dim=1), dim=-1, eps=1e-12)          # (N, D): one bounded negative per line
-        gathered = _AllGatherRows.apply(pooled, group) if group is not None else pooled        # (L, D), L = world * N
-        rank = dist.get_rank(group) if group is not None else 0
-        xl, yl = xn.to(dtype).contiguous(), yn.to(dtype).contiguous()
-        sim = _BmmNT.apply(xl, yl, 1.0 / T)                                                    # (N, S, S): sim[l, i, j] = x_i . y_j / T
-        cross = _MmNT.apply(yl.view(n * s, D), gathered.to(dtype).contiguous(), 1.0 / T)       # (N*S, L): y_j . p_l' / T
-        cross = cross.view(n, s, -1)
-        own = torch.arange(n, device=x.device) + rank * n
-        cross = cross.masked_fill(torch.nn.functional.one_hot(own, cross.shape[-1]).bool()[:, None, :], float("-inf"))
-        lse = torch.logsumexp(torch.cat([sim.transpose(1, 2), cross], dim=-1), dim=-1)         # per (line, column j): over i and l'
-        diag = torch.diagonal(sim, dim1=1, dim2=2)
-        return (lse - diag).mean(dim=1).mean()
+        return _NTXentCrossFn.apply(x, y, float(self.temperature), compute_dtype(), group)

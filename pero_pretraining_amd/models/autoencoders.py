@@ -67,6 +67,63 @@ class _QuantizeFn(torch.autograd.Function):
         return dq, None
 
 
+class _Project1x1Fn(torch.autograd.Function):
+    """Conv2d(C_in -> C_out, kernel 1) on (N, C_in, 1, T) features as ONE exact-f32 pero_gemm over the token rows (N*T, C_in): the
+    quantizer behind it decides by f32 distances, so the projection keeps f32 operands whatever the autocast mode."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        n, c, h, t = x.shape
+        rows = x.detach().permute(0, 2, 3, 1).reshape(-1, c).float().contiguous()
+        w2 = weight.detach().reshape(weight.shape[0], c).float().contiguous()
+        y = ops.gemm(rows, w2, bias=None if bias is None else bias.detach().float().contiguous())
+        ctx.save_for_backward(rows, w2)
+        ctx.shape, ctx.has_bias = x.shape, bias is not None
+        return y.view(n, h, t, -1).permute(0, 3, 1, 2).contiguous()
+
+    @staticmethod
+    def backward(ctx, dy):
+        rows, w2 = ctx.saved_tensors
+        n, c, h, t = ctx.shape
+        d2 = dy.permute(0, 2, 3, 1).reshape(-1, dy.shape[1]).float().contiguous()
+        dx = ops.gemm(d2, w2, trans_b=True).view(n, h, t, c).permute(0, 3, 1, 2).contiguous()
+        dw = ops.gemm(d2, rows, trans_a=True, trans_b=True).view(w2.shape[0], c, 1, 1)
+        db = d2.sum(0) if ctx.has_bias else None
+        return dx, dw, db
+
+
+class VQVAEQuantizer(torch.nn.Module):
+    """The quantizing middle of the reference's VQVAE (models/autoencoders.py:107-146): `encoder_projection_layer` (1x1 conv,
+    encoder channels -> embeddings_dim), `vq`, `decoder_projection_layer` (1x1 conv, embeddings_dim -> decoder channels), with the
+    reference's parameter names - a VQVAE checkpoint's `encoder_projection_layer.*`, `vq.*`, `decoder_projection_layer.*` entries
+    load with `load_state_dict(..., strict=False)` on the full file or strictly on the filtered one.  `quantize(x)` is the
+    reference's method: encoder features (N, C_enc, 1, T) -> (projected tokens (N, C_dec, 1, T), labels (N*T,)); the labels are
+    what masked pre-training predicts (scripts/produce_vqvae_labels.py:27-46).  The VGG encoder / decoder around it are outside the
+    hot path."""
+
+    def __init__(self, encoder_channels, decoder_channels, num_embeddings, embeddings_dim, commitment_cost=0.25, decay=0.99):
+        super().__init__()
+        self.encoder_projection_layer = torch.nn.Conv2d(encoder_channels, embeddings_dim, 1)     # parameter containers (same init / keys)
+        self.decoder_projection_layer = torch.nn.Conv2d(embeddings_dim, decoder_channels, 1)
+        self.num_embeddings = num_embeddings
+        self.embeddings_dim = embeddings_dim
+        self.vq = VectorQuantizer(num_embeddings, embeddings_dim, commitment_cost, decay)
+
+    def quantize(self, x):
+        if not x.is_cuda:
+            raise RuntimeError("pero_pretraining_amd VQVAEQuantizer runs on the GPU only (HIP kernels, no CPU fallback)")
+        x = _Project1x1Fn.apply(x, self.encoder_projection_layer.weight, self.encoder_projection_layer.bias)
+        tokens, labels = self.vq(x)
+        projected_tokens = _Project1x1Fn.apply(tokens, self.decoder_projection_layer.weight, self.decoder_projection_layer.bias)
+        return projected_tokens, labels
+
+    def labels(self, x):
+        """Labels only (the label-production path: no decoder projection)."""
+        with torch.no_grad():
+            x = _Project1x1Fn.apply(x, self.encoder_projection_layer.weight, self.encoder_projection_layer.bias)
+            return self.vq(x)[1]
+
+
 def kmeans_labels(features, centroids):
     """Feature-Quantization labels (scripts/produce_kmeans_labels.py:72-79): features (N, F, T), centroids (K, F)
     -> (N, T) int64 assignments.  argmin of the true L2 distance == argmin of the squared expanded form used by the

@@ -412,6 +412,32 @@ def ntxent_cols(sim, want_grad_dtype=None):
     return loss, line_loss, dsim
 
 
+def ntxent_cols_cross(sim, cross, own0, grad_dtype):
+    """sim (lines, S, S) f32, cross (lines*S, L) f32 -> (loss [1], line_loss, dsim, dcross) - see pero_ntxent_cols_cross."""
+    lines, S, _ = sim.shape
+    L = cross.shape[1]
+    line_loss = torch.empty(lines, device=sim.device, dtype=torch.float32)
+    loss = torch.empty(1, device=sim.device, dtype=torch.float32)
+    dsim = torch.empty(sim.shape, device=sim.device, dtype=grad_dtype)
+    dcross = torch.empty(cross.shape, device=sim.device, dtype=grad_dtype)
+    call("pero_ntxent_cols_cross", ptr(sim), ptr(cross), ptr(line_loss), ptr(loss), ptr(dsim), ptr(dcross), lines, S, L, int(own0),
+         dt(grad_dtype), stream())
+    return loss, line_loss, dsim, dcross
+
+
+def line_mean(x2, lines, S):
+    """x2 (lines*S, d) -> f32 (lines, d): mean over the rows of each line."""
+    out = torch.empty((lines, x2.shape[1]), device=x2.device, dtype=torch.float32)
+    call("pero_line_mean", ptr(x2), ptr(out), lines, S, x2.shape[1], dt(x2), stream())
+    return out
+
+
+def add_line_rows_(dst2, src, lines, S, scale):
+    """dst2 (lines*S, d) += scale * src (lines, d) f32, row-broadcast per line; in place."""
+    call("pero_add_line_rows", ptr(dst2), ptr(src), lines, S, dst2.shape[1], float(scale), dt(dst2), stream())
+    return dst2
+
+
 MAX_TOPK = 8
 
 

@@ -327,3 +327,59 @@ def test_config4_vicreg_at_d4096_bf16_syrk_against_f32_mode_and_oracle():
     for k in ("loss", "loss.variance", "loss.invariance", "loss.covariance"):
         assert abs(float(f32[k]) - float(oref[k])) < 1e-4 * abs(float(oref[k])) + 1e-7, (k, float(f32[k]), float(oref[k]))
         assert abs(float(b16[k]) - float(oref[k])) < 2e-2 * abs(float(oref[k])) + 1e-6, (k, float(b16[k]), float(oref[k]))
+
+
+def test_mlp_head_at_its_real_size():
+    """The reference's default MLPHead - Linear 512 -> 8192, ReLU, Linear 8192 -> 8192, ReLU, Linear 8192 -> 8192, 138.4 M parameters
+    (joint_embedding_pretraining/model.py:79-115) - at its real size.  (a) f32 parity mode on a 64-row subset against the CPU restatement
+    of the same Sequential (1e-4 on the outputs, 1e-3 of the largest entry on every gradient); (b) bf16 on 8192 rows (32 lines of 256
+    positions: the 256x256x64 tile kernels with the ReLU / gate epilogues) against the same rows in 512-row sub-batches (the small-shape
+    kernels that g19 pins): rows are independent, so outputs agree to bf16 rounding and the weight gradients are the sums."""
+    import pero_pretraining_amd as P
+    from pero_pretraining_amd.joint_embedding_pretraining.model import MLPHead, init_head
+    torch.manual_seed(11)
+    head = init_head({"type": "mlp"})          # the reference's defaults
+    assert isinstance(head, MLPHead) and sum(p.numel() for p in head.parameters()) == 512 * 8192 + 8192 + 2 * (8192 * 8192 + 8192)
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(1, 64, 512, generator=g)
+    # (a) f32, 64 rows, vs torch CPU arithmetic of the same layers (what oracle.mlp_head restates)
+    xr = x.clone().requires_grad_(True)
+    ref = head.layers(xr.reshape(64, 512))
+    gy = torch.randn(64, 8192, generator=g) / 64
+    (ref * gy).sum().backward()
+    gref = {k: p.grad.clone() for k, p in head.named_parameters()}
+    head.zero_grad()
+    head = head.cuda()
+    xg = x.cuda().requires_grad_(True)
+    out = head(xg)
+    assert float((out.detach().cpu().reshape(64, -1) - ref.detach()).abs().max()) < 1e-4 * max(1.0, float(ref.abs().max()))
+    (out.reshape(64, -1) * gy.cuda()).sum().backward()
+    assert float((xg.grad.cpu() - xr.grad).abs().max()) < 1e-3 * float(xr.grad.abs().max())
+    for k, p in head.named_parameters():
+        assert float((p.grad.cpu() - gref[k]).abs().max()) < 1e-3 * max(float(gref[k].abs().max()), 1e-8), k
+    del gref, ref
+    # (b) bf16, 8192 rows against 512-row sub-batches
+    rows, sub = 8192, 512
+    xb = (torch.randn(rows // 256, 256, 512, generator=g)).cuda()
+    gyb = (torch.randn(rows, 8192, generator=g) / rows).cuda()
+
+    def run(sl):
+        head.zero_grad()
+        xs = xb.reshape(rows, 512)[sl].reshape(-1, 256, 512).clone().requires_grad_(True)
+        with P.autocast(True):
+            y = head(xs)
+        (y.reshape(-1, 8192).float() * gyb[sl]).sum().backward()
+        return y.detach().reshape(-1, 8192), xs.grad.reshape(-1, 512).clone(), {k: p.grad.detach().float().clone() for k, p in head.named_parameters()}
+
+    y_full, dx_full, g_full = run(slice(0, rows))
+    acc = None
+    for s0 in range(0, rows, sub):
+        sl = slice(s0, s0 + sub)
+        y, dx, gsub = run(sl)
+        scale = float(y.float().abs().max())
+        assert float((y.float() - y_full[sl].float()).abs().max()) <= 1.6e-2 * scale, s0          # <= 2 bf16 ulps at the top
+        assert float((dx.float() - dx_full[sl].float()).abs().max()) <= 2e-2 * float(dx_full[sl].float().abs().max()), s0
+        acc = gsub if acc is None else {k: acc[k] + gsub[k] for k in gsub}
+    for k, want in acc.items():
+        rel = float((g_full[k] - want).norm() / want.norm().clamp_min(1e-12))
+        assert rel <= 2e-2, (k, rel)

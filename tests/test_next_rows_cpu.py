@@ -128,3 +128,29 @@ def test_label_text_and_record_formats(golden, tmp_path):
     assert store[b"         6"] == ('{"image": "b/line_1", "labels": [' + ", ".join(f'"{v}"' for v in data["b/line_1"]) + "]}").encode()
     assert L.parse_label_record(store[b"         7"]) == ("c-2.png", [str(data["c-2.png"][0])])
     assert L.parse_label_record(b'{"images": ["a", "b"], "labels": ["1"]}') == (["a", "b"], ["1"])
+
+
+def test_collator_host_masks_follow_the_reference_slicing_semantics():
+    """BatchCreator._host_masks (the numpy twin of csrc/collate.hip's mask kernel that rides along with the device masks): exhaustive small
+    case against the reference's slice arithmetic (common/dataloader.py:92-96, 124-138), negative / clamped shifts included."""
+    import numpy as np
+    from pero_pretraining_amd.common.dataloader import BatchCreator
+    S, sub = 6, 8
+    cases = [(w1, w2, a, b, c) for w1 in (8, 17, 40) for w2 in (8, 33) for a in range(0, 5) for b in range(0, 5) for c in (0, -7, 3, 9)]
+    im1, im2, sm1, sm2 = BatchCreator._host_masks([c[0] for c in cases], [c[2] for c in cases], [c[1] for c in cases], [c[3] for c in cases],
+                                                  [c[4] for c in cases], S, sub)
+    for i, (a_w, b_w, a, b, cs) in enumerate(cases):
+        e1 = np.ones(S, np.uint8); e1[:a] = 0; e1[a + int(np.ceil(a_w / sub)):] = 0
+        e2 = np.ones(S, np.uint8); e2[:b] = 0; e2[b + int(np.ceil(b_w / sub)):] = 0
+        sh = cs + a - b
+        s1 = np.zeros(S, np.uint8)
+        if sh < 0:
+            s1[:sh] = 1
+        else:
+            s1[sh:] = 1
+        s2 = s1[::-1].copy()
+        s1[(s1 == 1) & (e1 == 0)] = 2; s2[(s2 == 1) & (e2 == 0)] = 2
+        assert np.array_equal(im1[i], e1) and np.array_equal(im2[i], e2), cases[i]
+        assert np.array_equal(sm1[i], s1) and np.array_equal(sm2[i], s2), cases[i]
+    only1 = BatchCreator._host_masks([16, 40], [1, 0], None, None, [0, 0], S, sub)
+    assert only1[1] is None and only1[0].tolist() == [[0, 1, 1, 0, 0, 0], [1, 1, 1, 1, 1, 0]]

@@ -145,3 +145,14 @@ def test_joint_tiny(golden):
     assert np.abs(o2.numpy() - g["output2"]).max() < 2e-5
     for k in ("loss", "loss.variance", "loss.invariance", "loss.covariance"):
         assert abs(float(res[k]) - float(g[k])) < 5e-6 * abs(float(g[k])) + 1e-7, k
+
+
+def test_vqvae_quantize_oracle_matches_reference(golden):
+    """g20: the reference's own VQVAE.quantize (1x1 projection -> VectorQuantizer -> 1x1 projection, models/autoencoders.py:142-146)."""
+    g = golden("g20_vqvae_quantize.npz")
+    sd = {k[3:]: g[k] for k in g.files if k.startswith("sd.")}
+    rows, labels, tok = O.vqvae_quantize(g["features"], sd)
+    want = torch.from_numpy(g["projected"]).permute(0, 2, 3, 1).reshape(-1, int(g["embeddings_dim"]))
+    assert float((rows - want).abs().max()) < 1e-5
+    assert np.array_equal(labels.numpy(), g["labels"])
+    assert float((tok - torch.from_numpy(g["tokens"])).abs().max()) < 1e-5

@@ -169,3 +169,25 @@ def test_joint_trainer_three_steps_match_the_reference_trainer(golden):
                 assert np.abs(got - ref).max() <= 3 * 1e-3 + 1e-6, k
                 continue
             assert np.abs(got - ref).max() < 1e-3 and np.abs(got - ref).mean() < 1e-4, (k, float_images, np.abs(got - ref).max())
+
+
+@pytest.mark.gpu
+def test_vqvae_quantize_matches_reference(golden):
+    """g20: `VQVAEQuantizer.quantize` (the 1x1 encoder projection in front of the codebook argmin, the straight-through tokens, the 1x1
+    decoder projection) against the reference's own VQVAE.quantize: labels bit-exact (smallest relative margin in the fixture 5e-4),
+    projected tokens 1e-5; the reference's state_dict entries load by name."""
+    from pero_pretraining_amd.models.autoencoders import VQVAEQuantizer
+    g = golden("g20_vqvae_quantize.npz")
+    m = VQVAEQuantizer(int(g["encoder_channels"]), int(g["decoder_channels"]), int(g["num_embeddings"]), int(g["embeddings_dim"]))
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd.")}
+    assert set(sd) == set(m.state_dict())
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    x = torch.from_numpy(g["features"]).cuda().requires_grad_(True)
+    tokens, labels = m.quantize(x)
+    assert labels.dtype == torch.int64 and np.array_equal(labels.cpu().numpy(), g["labels"])
+    assert np.abs(tokens.detach().cpu().numpy() - g["tokens"]).max() < 1e-5
+    assert np.array_equal(m.labels(x.detach()).cpu().numpy(), g["labels"])
+    # gradients flow straight through the quantizer into both projections (autoencoders.py:239)
+    tokens.square().mean().backward()
+    assert x.grad is not None and float(x.grad.abs().max()) > 0 and m.encoder_projection_layer.weight.grad is not None
