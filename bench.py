@@ -328,7 +328,7 @@ def leg_joint(timer, device, kind, pairs, steps, repeats, world, rank, variant=N
             "variant": {"vicreg": {None: "per-rank statistics", "global": "exact global statistics (two extra all-reduces: D + 1 floats, D x D f32)"},
                         "ntxent": {None: "per-line negatives (the reference's loss)", "cross": "cross-rank negatives: pooled embeddings all-gathered"}}[kind][variant],
             "ms_per_step": round(med / steps * 1e3, 3), "line_pairs_per_s": round(world * pairs * steps / med, 1),
-            "repeats_ms_per_step": [round(e / steps * 1e3, 3) for e in els], "loss": round(float(loss_v), 5),
+            "repeats_ms_per_step": [round(e / steps * 1e3, 3) for e in els], "loss": round(float(loss_v.detach()), 5),
             "distributed": {"world_size": world, "backend": dist.get_backend() if dist.is_initialized() else None},
             "roofline": roof}
 

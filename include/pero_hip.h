@@ -157,6 +157,10 @@ int pero_masked_ce_fwd(const void* logits, const int64_t* labels, const int64_t*
 int pero_masked_ce_bwd(const void* logits, const int64_t* labels, const int64_t* mask, float unmasked_weight,
                        const float* dloss, const float* work, void* dlogits, int64_t rows, int64_t V, int dtype,
                        void* stream);
+/* pero_masked_ce_fwd for a caller that knows the rows with mask == 1 (index: int64 device list of n_idx rows) and passes
+ * unmasked_weight "None": only those rows are visited (one workgroup each instead of one per position); same loss bits. */
+int pero_masked_ce_fwd_rows(const void* logits, const int64_t* labels, const int64_t* mask, const int64_t* index, int64_t n_idx,
+                            float* loss_out, float* work, int64_t rows, int64_t V, int dtype, void* stream);
 /* The same gradient in COMPACT form: dlogits_rows (dtype, n_rows_out x V) row i = the gradient row of logits row index[i] for
  * i < n_idx (bit-identical to row index[i] of pero_masked_ce_bwd's result), zero rows for n_idx <= i < n_rows_out (padding up to whole
  * GEMM tiles).  With unmasked_weight "None" every row outside mask == 1 of the dense gradient is an exact zero, so the head's
@@ -182,6 +186,8 @@ int pero_cast_bf16_f32(const void* src, float* dst, int64_t n, void* stream);
 int pero_cast_pad_f32_bf16(const float* src, void* dst, int64_t rows, int64_t cols, int64_t ld_dst, void* stream);
 /* dst[r][c] += src[r][c] for c < cols (f32, row pitches ld_dst / ld_src) */
 int pero_add_rows2d(float* dst, const float* src, int64_t rows, int64_t cols, int64_t ld_dst, int64_t ld_src, void* stream);
+/* nbytes of zeros at p */
+int pero_zero_fill(void* p, int64_t nbytes, void* stream);
 /* y = x * scale (in place allowed), dtype elements */
 int pero_scale(void* x, int64_t n, float scale, int dtype, void* stream);
 

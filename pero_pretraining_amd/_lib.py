@@ -38,6 +38,8 @@ SIGNATURES = {
     "pero_softmax_bwd": [_vp, _vp, _vp, _i64, _i64, _f32, _i32, _vp],
     "pero_masked_ce_fwd": [_vp, _vp, _vp, _f32, _vp, _vp, _i64, _i64, _i32, _vp],
     "pero_masked_ce_bwd": [_vp, _vp, _vp, _f32, _vp, _vp, _vp, _i64, _i64, _i32, _vp],
+    "pero_masked_ce_fwd_rows": [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _vp],
+    "pero_zero_fill": [_vp, _i64, _vp],
     "pero_masked_ce_bwd_rows": [_vp, _vp, _vp, _f32, _vp, _vp, _vp, _i64, _i64, _vp, _i64, _i64, _i32, _vp],
     "pero_colsum": [_vp, _vp, _i64, _i64, _i64, _i32, _vp],
     "pero_cast_f32_bf16": [_vp, _vp, _i64, _vp],

@@ -1192,6 +1192,12 @@ __device__ __forceinline__ void lh_store_matrix(const f16v (&acc)[4], unsigned s
   lh_ds_write4<384>(pa, sums[3]);
 }
 
+#ifndef LH_STAGGER
+#define LH_STAGGER 0
+#endif
+#ifndef LH_STAGGER_K
+#define LH_STAGGER_K 0
+#endif
 #ifndef LH_QPOOL
 #define LH_QPOOL 4     // fragment register sets of phase Q (LH_QPOOL - 1 in flight): the kernel is bound by its memory pipeline, not by LDS latency
 #endif
@@ -1354,6 +1360,10 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_lh_k(const bf16raw* qkv, cons
         asm volatile("" : "+v"(gf[0]), "+v"(gf[1]), "+v"(gf[2]), "+v"(gf[3]), "+v"(gf[4]), "+v"(gf[5]), "+v"(gf[6]), "+v"(gf[7]), "+v"(lq), "+v"(dsum) :: "memory");
         lh_barrier();            // all four halves of every thread have landed: the halves below need no further barrier
         if (!first) reduce_partials(uprev);   // the previous unit's bias partials: every wave has left its epilogue (this barrier)  [1]
+        // the two waves of a SIMD run the same instruction sequence from the same barrier: left alone they want the matrix pipe at the same
+        // time and the vector ALU at the same time.  Waves 4-7 start one MFMA cluster late (LH_STAGGER x 64 cycles), so that one wave's
+        // exponentials run under the other's MFMAs (s_setprio 1 inside the clusters keeps them apart)
+        if (LH_STAGGER && wave >= 4) __builtin_amdgcn_s_sleep(LH_STAGGER);
       }
       LH_ST(3 * h + 1);
       unsigned stage = s0 + h * LH_SLOT;
@@ -1442,6 +1452,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_lh_k(const bf16raw* qkv, cons
       lh_barrier();
       LH_ST(15 + 3 * j8);
       if (j8 >= 1 && j8 <= 4) issue_T(j8 + 3);
+      if (LH_STAGGER_K && wave >= 4) __builtin_amdgcn_s_sleep(LH_STAGGER_K);
       const unsigned stage = s0 + 2 * LH_SLOT + (j8 & 3) * 16384;
       const unsigned stb = s0 + LH_STATS + (j8 & 3) * 256, sto = 16 * h5;
       bf8v fr[LH_KPOOL];

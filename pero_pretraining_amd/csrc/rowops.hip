@@ -428,9 +428,9 @@ extern "C" int pero_softmax_bwd(const void* p, const float* dp, void* ds, int64_
 // forward: per-row loss -> work[row], per-row logsumexp -> work[rows + 8 + row]
 template <typename T>
 __global__ __launch_bounds__(256) void ce_rows_k(const T* logits, const int64_t* labels, const int64_t* mask, float uw,
-                                                 float* work, long long rows, int V) {
+                                                 float* work, long long rows, int V, const int64_t* index) {
   __shared__ float red[4];
-  const long long row = blockIdx.x;
+  const long long row = index ? index[blockIdx.x] : blockIdx.x;   // (compact form: the caller lists the rows that take part)
   const int tid = threadIdx.x;
   const long long lab = labels[row];
   const long long mk = mask[row];
@@ -601,12 +601,26 @@ extern "C" int pero_masked_ce_fwd(const void* logits, const int64_t* labels, con
   PERO_REQUIRE(logits && labels && mask && loss_out && work, "pero_masked_ce_fwd: null pointer");
   PERO_REQUIRE(rows > 0 && V > 0 && rows < 16777216, "pero_masked_ce_fwd: bad sizes");
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == PERO_F32) hipLaunchKernelGGL((ce_rows_k<float>), dim3((unsigned)rows), dim3(256), 0, st, (const float*)logits, labels, mask, unmasked_weight, work, (long long)rows, (int)V);
-  else if (dtype == PERO_BF16) hipLaunchKernelGGL((ce_rows_k<bf16raw>), dim3((unsigned)rows), dim3(256), 0, st, (const bf16raw*)logits, labels, mask, unmasked_weight, work, (long long)rows, (int)V);
+  if (dtype == PERO_F32) hipLaunchKernelGGL((ce_rows_k<float>), dim3((unsigned)rows), dim3(256), 0, st, (const float*)logits, labels, mask, unmasked_weight, work, (long long)rows, (int)V, (const int64_t*)nullptr);
+  else if (dtype == PERO_BF16) hipLaunchKernelGGL((ce_rows_k<bf16raw>), dim3((unsigned)rows), dim3(256), 0, st, (const bf16raw*)logits, labels, mask, unmasked_weight, work, (long long)rows, (int)V, (const int64_t*)nullptr);
   else PERO_REQUIRE(false, "pero_masked_ce_fwd: bad dtype");
   hipMemsetAsync(work + rows + 2, 0, sizeof(float), st);  // the reduction's ticket
   hipLaunchKernelGGL(ce_final_k, dim3(CE_PARTS), dim3(256), 0, st, labels, mask, unmasked_weight, work, loss_out, (long long)rows);
   PERO_CHECK_LAUNCH("pero_masked_ce_fwd");
+  return PERO_OK;
+}
+extern "C" int pero_masked_ce_fwd_rows(const void* logits, const int64_t* labels, const int64_t* mask, const int64_t* index, int64_t n_idx,
+                                       float* loss_out, float* work, int64_t rows, int64_t V, int dtype, void* stream) {
+  PERO_REQUIRE(logits && labels && mask && index && loss_out && work, "pero_masked_ce_fwd_rows: null pointer");
+  PERO_REQUIRE(rows > 0 && V > 0 && rows < 16777216 && n_idx > 0 && n_idx <= rows, "pero_masked_ce_fwd_rows: bad sizes");
+  hipStream_t st = (hipStream_t)stream;
+  // ce_final_k reads work[r] of every row with mask == 1 (all listed) and, into a sum this mode never uses, of the rows with mask == 0
+  if (dtype == PERO_F32) hipLaunchKernelGGL((ce_rows_k<float>), dim3((unsigned)n_idx), dim3(256), 0, st, (const float*)logits, labels, mask, -1.0f, work, (long long)rows, (int)V, index);
+  else if (dtype == PERO_BF16) hipLaunchKernelGGL((ce_rows_k<bf16raw>), dim3((unsigned)n_idx), dim3(256), 0, st, (const bf16raw*)logits, labels, mask, -1.0f, work, (long long)rows, (int)V, index);
+  else PERO_REQUIRE(false, "pero_masked_ce_fwd_rows: bad dtype");
+  hipMemsetAsync(work + rows + 2, 0, sizeof(float), st);  // the reduction's ticket
+  hipLaunchKernelGGL(ce_final_k, dim3(CE_PARTS), dim3(256), 0, st, labels, mask, -1.0f, work, loss_out, (long long)rows);
+  PERO_CHECK_LAUNCH("pero_masked_ce_fwd_rows");
   return PERO_OK;
 }
 extern "C" int pero_masked_ce_bwd(const void* logits, const int64_t* labels, const int64_t* mask, float unmasked_weight,

@@ -91,8 +91,8 @@ class _VICRegFn(torch.autograd.Function):
         # gradient AVERAGE over ranks would divide the sum of those parts by world, so the seed is multiplied by world
         gdev = g.detach().reshape(1).to(torch.float32) * ctx.seed
         dzc = ops.gemm(zc, G)  # (m_pad, D): d(wv*var + wc*cov)/d zc
-        dx = torch.zeros_like(x2)
-        dy = torch.zeros_like(y2)
+        dx = ops.zeros(x2.shape, x2.device, x2.dtype)
+        dy = ops.zeros(y2.shape, y2.device, y2.dtype)
         ops.scatter_add_rows_scaled(dzc[:n1], jx, dx, gdev)
         ops.scatter_add_rows_scaled(dzc[n1:m], jy, dy, gdev)
         ops.sqdiff_rows_bwd(x2, ix, y2, iy, dx, dy, gdev, inv_coef)

@@ -105,7 +105,7 @@ class _GatherTokensFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, drows):
         (index,) = ctx.saved_tensors
-        dx = torch.zeros(ctx.shape, device=drows.device, dtype=drows.dtype)
+        dx = ops.zeros(ctx.shape, drows.device, drows.dtype)
         ops.scatter_add_rows(drows.contiguous(), index, dx)
         return dx, None, None
 
@@ -140,7 +140,7 @@ class _HeadCEFn(torch.autograd.Function):
         logits = F.linear_fwd(x2, weight, bias, dtype)
         lab = labels.reshape(-1).to(device=x2.device, dtype=torch.int64).contiguous()
         msk = mask.reshape(-1).to(device=x2.device, dtype=torch.int64).contiguous()
-        loss, work = ops.masked_ce_fwd(logits, lab, msk, None)
+        loss, work = ops.masked_ce_fwd_rows(logits, lab, msk, index)     # the listed rows only: same bits as the all-rows form
         ctx.save_for_backward(x2, logits, lab, msk, work, index)
         ctx.weight, ctx.bias, ctx.dtype, ctx.shape = weight, bias, dtype, tokens.shape
         ctx.mark_non_differentiable(logits)
@@ -157,7 +157,7 @@ class _HeadCEFn(torch.autograd.Function):
         dxm = F.linear_bwd(dlog, xm, ctx.weight, ctx.bias, ctx.dtype, need_dx=ctx.needs_input_grad[0])
         dx = None
         if dxm is not None:
-            dx = torch.zeros_like(x2)
+            dx = ops.zeros(x2.shape, x2.device, x2.dtype)
             ops.scatter_add_rows(dxm, index, dx)                            # reads the first n rows of dxm
             dx = dx.view(ctx.shape)
         return dx, None, None, None, None, None, None

@@ -194,6 +194,24 @@ def masked_ce_fwd(logits, labels, mask, unmasked_weight=None):
     return loss, work
 
 
+def masked_ce_fwd_rows(logits, labels, mask, index):
+    """masked_ce_fwd with unmasked_weight None for a caller that lists the rows with mask == 1 (int64 device tensor): same bits."""
+    rows, V = logits.shape
+    loss = torch.empty(1, device=logits.device, dtype=torch.float32)
+    work = torch.empty(2 * rows + 8 + 256, device=logits.device, dtype=torch.float32)
+    call("pero_masked_ce_fwd_rows", ptr(logits), ptr(labels), ptr(mask), ptr(index), index.numel(), ptr(loss), ptr(work), rows, V,
+         dt(logits), stream())
+    return loss, work
+
+
+def zeros(shape, device, dtype):
+    """A zero tensor filled by the library's linear fill kernel (torch's elementwise fill runs at a third of its rate)."""
+    t = torch.empty(shape, device=device, dtype=dtype)
+    if t.numel():
+        call("pero_zero_fill", ptr(t), t.numel() * t.element_size(), stream())
+    return t
+
+
 def masked_ce_bwd(logits, labels, mask, work, unmasked_weight=None, dloss=None):
     rows, V = logits.shape
     dlogits = torch.empty_like(logits)

@@ -385,6 +385,10 @@ def test_masked_ce(ops, dtype, uw):
     assert rel_err(dl, lr.grad) < (1e-5 if dtype == torch.float32 else 2 ** -7)
     dl2 = ops.masked_ce_bwd(dev(logits), dev(labels), dev(mask), work, uw, dloss=torch.full((1,), 0.5, device="cuda"))
     assert rel_err(dl2, 0.5 * lr.grad) < (1e-5 if dtype == torch.float32 else 2 ** -7)
+    if uw is None:   # the compact forward (pero_masked_ce_fwd_rows: only the listed mask == 1 rows are visited): the same bits
+        loss_c, work_c = ops.masked_ce_fwd_rows(dev(logits), dev(labels), dev(mask), dev(torch.nonzero(mask == 1).reshape(-1)))
+        assert torch.equal(loss_c, loss)
+        assert torch.equal(ops.masked_ce_bwd(dev(logits), dev(labels), dev(mask), work_c, uw), dl)
     # compact form (pero_masked_ce_bwd_rows): the listed rows bit for bit, zero padding rows behind; a listed row that takes no
     # part in the loss is a zero row
     sel = torch.nonzero(mask == 1).reshape(-1)

@@ -15,9 +15,10 @@ dqkv = torch.empty_like(qkv)
 dbias = torch.zeros(3 * d, device="cuda")
 work = torch.zeros(3 * n * h * 2 * 128, device="cuda")
 V = ctypes.c_void_p
-paths = sorted(glob.glob(os.path.join(R, "tools/abl/liblh_*.so")), key=lambda p: int(re.findall(r"_(\d+)\.so", p)[0]))
+paths = sorted(glob.glob(os.path.join(R, "tools/abl/liblh_*.so")))
 for path in paths + paths:
     lib = ctypes.CDLL(path)
+    ctypes.c_int.in_dll(lib, "g_attn_lh").value = 1      # (the persistent kernel is an option: default off)
     f = lib.pero_attention_bwd
     f.argtypes = [V] * 8 + [ctypes.c_int64] * 4 + [ctypes.c_int, V]
     args = (qkv.data_ptr(), None, dout.data_ptr(), lse.data_ptr(), dvec.data_ptr(), dqkv.data_ptr(), dbias.data_ptr(), work.data_ptr(), n, s, h, hd, 1,

@@ -17,6 +17,7 @@ dbias = torch.zeros(3 * d, device="cuda")
 work = torch.zeros(3 * n * h * 2 * 128, device="cuda")
 lib = ctypes.CDLL(os.path.join(R, "tools/abl/libattn_stamp.so"))
 V = ctypes.c_void_p
+ctypes.c_int.in_dll(lib, "g_attn_lh").value = 1
 f = lib.pero_attention_bwd
 f.argtypes = [V] * 8 + [ctypes.c_int64] * 4 + [ctypes.c_int, V]
 args = (qkv.data_ptr(), None, dout.data_ptr(), lse.data_ptr(), dvec.data_ptr(), dqkv.data_ptr(), dbias.data_ptr(), work.data_ptr(), n, s, h, hd, 1,
