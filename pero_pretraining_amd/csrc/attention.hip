@@ -229,6 +229,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_k(const bf16raw* qkv, bf16raw
   }
 }
 
+
 // heads per workgroup: as many as keep >= 2 workgroups per CU busy
 static int attn_heads_per_block(long long N, long long S, long long nh) {
   const int num_cus = pero_num_cus();
@@ -238,6 +239,8 @@ static int attn_heads_per_block(long long N, long long S, long long nh) {
   return hpb;
 }
 
+extern int g_attn_pipe;
+__global__ void attn_fwd_p_k(const bf16raw* qkv, bf16raw* out, float* lse2, int S, int nh, int hpb, float c);   // (defined behind the asm helpers)
 extern "C" int pero_attention_fwd(const void* qkv, void* out, float* lse, int64_t N, int64_t S, int64_t num_heads,
                                   int64_t head_dim, int dtype, void* stream) {
   PERO_REQUIRE(qkv && out && lse, "pero_attention_fwd: null pointer");
@@ -245,10 +248,15 @@ extern "C" int pero_attention_fwd(const void* qkv, void* out, float* lse, int64_
                "pero_attention_fwd: fused kernel needs bf16, head_dim 128, S %% 128 == 0 (got hd=%lld S=%lld)", (long long)head_dim, (long long)S);
   PERO_REQUIRE(aligned16(qkv) && aligned16(out), "pero_attention_fwd: 16-byte alignment");
   PERO_LDS_ATTR(attn_fwd_k, 2 * AT_TILE_BYTES);
+  PERO_LDS_ATTR(attn_fwd_p_k, 2 * AT_TILE_BYTES);
   const float c = (float)(1.4426950408889634 / sqrt((double)head_dim));
   const int hpb = attn_heads_per_block(N, S, num_heads);
-  hipLaunchKernelGGL(attn_fwd_k, dim3((unsigned)(N * (num_heads / hpb) * (S / 128))), dim3(256), 2 * AT_TILE_BYTES, (hipStream_t)stream,
-                     (const bf16raw*)qkv, (bf16raw*)out, lse, (int)S, (int)num_heads, hpb, c);
+  if (g_attn_pipe)
+    hipLaunchKernelGGL(attn_fwd_p_k, dim3((unsigned)(N * (num_heads / hpb) * (S / 128))), dim3(256), 2 * AT_TILE_BYTES, (hipStream_t)stream,
+                       (const bf16raw*)qkv, (bf16raw*)out, lse, (int)S, (int)num_heads, hpb, c);
+  else
+    hipLaunchKernelGGL(attn_fwd_k, dim3((unsigned)(N * (num_heads / hpb) * (S / 128))), dim3(256), 2 * AT_TILE_BYTES, (hipStream_t)stream,
+                       (const bf16raw*)qkv, (bf16raw*)out, lse, (int)S, (int)num_heads, hpb, c);
   PERO_CHECK_LAUNCH("pero_attention_fwd");
   return PERO_OK;
 }
@@ -1571,6 +1579,194 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_lh_k(const bf16raw* qkv, cons
   }
 #endif
 }
+
+// ---- forward, pipelined operand reads (round 3; see the note in front of the `_p` backward bodies).  hipcc's schedule of attn_fwd_k
+// puts an `s_waitcnt vmcnt(0)` right behind the counted vmcnt(8) at the loop top and another one in front of the V reads - the
+// K(u+1) tile issued after the scores is waited for before P V, the V(u) wait cannot be deferred - and serialises read -> wait -> MFMA.
+// Here every LDS access of the loop (fragments, the O staging of a head's last tile) is inline asm: 32 K row fragments for the scores
+// (six in flight), the first seven transposed V fragments in flight while the exponentials run, then rolling.  Same MFMAs in the
+// same order: out and lse are bit-identical to attn_fwd_k.
+#define FW_POOL 8
+__global__ __launch_bounds__(256, 2) void attn_fwd_p_k(const bf16raw* qkv, bf16raw* out, float* lse2, int S, int nh, int hpb, float c) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* kimg = smem;
+  unsigned char* vimg = smem + AT_TILE_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h5 = lane >> 5, r = lane & 31;
+  const int nqb = S >> 7, ngrp = nh / hpb;
+  int lg, qb;
+  attn_block_map(blockIdx.x, nqb, gridDim.x / nqb, lg, qb);
+  const int line = lg / ngrp, head0 = (lg % ngrp) * hpb;
+  const long long d = (long long)nh * 128, ld = 3 * d;
+  const bf16raw* lbase = qkv + (long long)line * S * ld;  // + head * 128 : q ; + d : k ; + 2d : v
+  const int q = qb * 128 + wave * 32 + r;  // this lane's query (both lane halves hold the same query)
+  const int nkt = S >> 7, units = hpb * nkt;
+
+  attn_glds_tile<false>(lbase + head0 * 128 + d, ld, kimg, wave, lane);
+  attn_glds_tile<true>(lbase + head0 * 128 + 2 * d, ld, vimg, wave, lane);
+
+  // this lane's Q row fragments by loads the compiler does not see (it waits vmcnt(0) for its own loads once LDS-DMA is in flight, which
+  // would also wait for the V tile the loop top lets fly): uniform base + 32-bit lane offset
+  bf8v qf[8];
+  const unsigned qoff = (unsigned)((long long)q * ld * 2 + 16 * h5);
+  auto load_q = [&](int head) {
+    const bf16raw* qb_ = lbase + head * 128;
+    at_static_for<0, 8>([&](auto kc) __attribute__((always_inline)) { constexpr int ks = decltype(kc)::value; lh_gload16<32 * ks>(qf[ks], qb_, qoff); });
+  };
+  load_q(head0);
+  // fragment addresses: K row fragment (key 32 t + r, k-step ks) = ka0 ^ (32 ks) + 8192 t;  V^T fragment (keys 32 t + 16 sub + .., head-dim
+  // tile dt) = va0 ^ (64 dt) + 8192 t + 4096 sub (second read + 2048)
+  const unsigned kbase = at_lds_addr(kimg), vbase = at_lds_addr(vimg);
+  const unsigned ka0 = (unsigned)(r * 256 + ((h5 ^ (r & 15)) << 4));
+  unsigned va0;
+  {
+    const int i = lane & 15, g1 = (lane >> 4) & 1;
+    const int key = 4 * h5 + (i >> 2);
+    va0 = (unsigned)(key * 256 + ((key & 3) << 6) + g1 * 32 + (i & 3) * 8);
+  }
+  f16v o[4];
+#pragma unroll
+  for (int t = 0; t < 4; t++) o[t] = (f16v){0};
+  float m = -INFINITY, l = 0.f;
+
+  for (int u = 0; u < units; u++) {
+    const int head = head0 + u / nkt, kt = u % nkt;
+    if (u > 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // K(u) (and the head's Q rows); V(u), the newest eight, may still fly
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]), "+v"(qf[4]), "+v"(qf[5]), "+v"(qf[6]), "+v"(qf[7]) :: "memory");   // (older than V(u): landed)
+    lh_barrier();  // K(u) landed
+    bf8v fr[FW_POOL];
+    f16v s[4];
+    // ---- S^T = K Q^T: 32 row fragments (t, ks), six in flight
+    auto issue_k = [&](auto jc) __attribute__((always_inline)) {
+      constexpr int j = decltype(jc)::value;
+      constexpr int t = j >> 3, ks = j & 7;
+      at_rd128x<t * 8192, 32 * ks>(fr[j % FW_POOL], ka0, kbase);
+    };
+    at_static_for<0, 6>(issue_k);
+    AT_PRIO(1);
+    at_static_for<0, 32>([&](auto jc) __attribute__((always_inline)) {
+      constexpr int j = decltype(jc)::value;
+      constexpr int t = j >> 3, ks = j & 7;
+      if constexpr (j + 6 < 32) issue_k(std::integral_constant<int, j + 6>{});
+      constexpr int after = (31 - j) < 6 ? (31 - j) : 6;
+      at_wait_lgkm<after>(fr[j % FW_POOL]);
+      if constexpr (ks == 0) s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[j % FW_POOL], qf[0], (f16v){0}, 0, 0, 0);
+      else s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[j % FW_POOL], qf[ks], s[t], 0, 0, 0);
+    });
+    AT_PRIO(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // own part of V(u)
+    lh_barrier();  // every wave is done with the K image; V(u) landed
+    if (u + 1 < units) {
+      const int nhd = head0 + (u + 1) / nkt, nkt_i = (u + 1) % nkt;
+      attn_glds_tile<false>(lbase + nhd * 128 + d + (long long)nkt_i * 128 * ld, ld, kimg, wave, lane);
+    }
+    // ---- transposed V fragments: m = (t, sub, dt), seven in flight; the first seven go out in front of the softmax arithmetic
+    auto issue_v = [&](auto mc) __attribute__((always_inline)) {
+      constexpr int mm = decltype(mc)::value;
+      constexpr int t = mm >> 3, sub = (mm >> 2) & 1, dt = mm & 3;
+      at_rdtrx<t * 8192 + sub * 4096, t * 8192 + sub * 4096 + 2048, 64 * dt>(fr[mm % FW_POOL], va0, va0, vbase);
+    };
+    at_static_for<0, 7>(issue_v);
+
+    // ---- online softmax, all lane-local except one lane^32 exchange per reduction
+    float mx = s[0][0];
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) mx = fmaxf(mx, s[t][e]);
+    {   // lanes l and l + 32 hold the two halves of a query's scores: v_permlane32_swap instead of a trip through the LDS crossbar
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+      mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    }
+    const float mn = fmaxf(m, mx);
+    const float alpha = __builtin_amdgcn_exp2f((m - mn) * c);  // exp2(-inf) = 0 on a head's first tile
+    const float mc = mn * c;
+    float ps = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) {
+        const float p = __builtin_amdgcn_exp2f(fmaf(s[t][e], c, -mc));
+        s[t][e] = p;
+        ps += p;
+      }
+    {
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(ps), __float_as_uint(ps), false, false);
+      ps = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    }
+    l = l * alpha + ps;
+    m = mn;
+    if (kt != 0) {  // (a head's first tile: O is still zero)
+#pragma unroll
+      for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) o[t][e] *= alpha;
+    }
+
+    // ---- O^T += V^T P^T
+    AT_PRIO(1);
+    at_static_for<0, 32>([&](auto mc_) __attribute__((always_inline)) {
+      constexpr int mm = decltype(mc_)::value;
+      constexpr int t = mm >> 3, sub = (mm >> 2) & 1, dt = mm & 3;
+      if constexpr (mm + 7 < 32) issue_v(std::integral_constant<int, mm + 7>{});
+      constexpr int after = 2 * ((31 - mm) < 7 ? (31 - mm) : 7);
+      at_wait_lgkm<after>(fr[mm % FW_POOL]);
+      const bf8v pf = pack8(s[t], sub);
+      o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[mm % FW_POOL], pf, o[dt], 0, 0, 0);
+    });
+    AT_PRIO(0);
+    if (kt == nkt - 1) {
+      // ---- head finished: O[q][d] = o[dt][reg] / l, staged through the (now free) V image so that HBM sees whole 256-byte rows in
+      // 16-byte lanes.  Image: 128 rows x 256 B, 8-byte granule index XORed with (row & 31).  (LDS accesses by asm: see the note above)
+      lh_barrier();  // every wave is done with the V image
+      const float inv = 1.0f / l;
+      int qrow_l = wave * 32 + r, tid_l = tid;
+      asm volatile("" : "+v"(qrow_l), "+v"(tid_l));  // keep the staging addresses out of the unit loop's live set
+#pragma unroll
+      for (int dt = 0; dt < 4; dt++)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; g4++) {
+          const at_u2v w = {pack2bf(o[dt][4 * g4 + 0] * inv, o[dt][4 * g4 + 1] * inv), pack2bf(o[dt][4 * g4 + 2] * inv, o[dt][4 * g4 + 3] * inv)};
+          const int g = dt * 8 + 2 * g4 + h5;  // granule of d = dt*32 + 8*g4 + 4*h5
+          lh_ds_write8(vbase + qrow_l * 256 + ((g ^ (qrow_l & 31)) << 3), w);
+        }
+      // base-2 LSE of c*scores (both lane halves hold it and store it: same value, same address)
+      lh_gstore4(m * c + __builtin_amdgcn_logf(l), lse2 + ((long long)line * nh + head) * S, (unsigned)q * 4u);
+      lh_wait_lgkm_plain<0>();
+      lh_barrier();
+      {
+        const int ch = tid_l & 15;
+        at_u4v v[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          const int row = (tid_l >> 4) + 16 * i;
+          lh_ds_read16(v[i], vbase + row * 256 + ((ch ^ ((row & 31) >> 1)) << 4));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]) :: "memory");
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          const int row = (tid_l >> 4) + 16 * i;
+          at_u4v x = v[i];
+          if (row & 1) x = (at_u4v){v[i][2], v[i][3], v[i][0], v[i][1]};
+          lh_gstore16<0>(x, out + ((long long)line * S + qb * 128) * d + head * 128, (unsigned)(row * (int)d * 2 + ch * 16));
+        }
+      }
+      if (u + 1 < units) {  // next head: fresh statistics, its Q rows (the loads complete under the loop-top wait)
+#pragma unroll
+        for (int t = 0; t < 4; t++) o[t] = (f16v){0};
+        m = -INFINITY;
+        l = 0.f;
+        load_q(head + 1);
+      }
+    }
+    if (u + 1 < units) {
+      lh_barrier();  // every wave is done with the V image (and with the O staging reads)
+      const int nhd = head0 + (u + 1) / nkt, nkt_i = (u + 1) % nkt;
+      attn_glds_tile<true>(lbase + nhd * 128 + 2 * d + (long long)nkt_i * 128 * ld, ld, vimg, wave, lane);
+    }
+  }
+}
+
 
 int g_attn_bwd_pair = 1;  // pero_set_option("attn_bwd_pair", 0 / 1)
 int g_attn_lh = 0;        // pero_set_option("attn_lh", 0 / 1): S = 256 with D handed in and a bias gradient wanted -> the persistent (line, head) kernel
