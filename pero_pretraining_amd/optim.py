@@ -157,6 +157,12 @@ class FusedAdam(torch.optim.Optimizer):
             # backward write a fresh tensor) is copied in and relinked: stepping on the stale flat slice would be silent
             for p, o in zip(f["params"], f["offsets"]):
                 if p.grad is not None and p.grad.data_ptr() != f["g"].data_ptr() + 4 * o:
+                    if self.grad_scale != 1.0:
+                        # a data-parallel driver reduced the FLAT buffer during the backward: this detached gradient is this rank's
+                        # alone - copying it in would step every rank on its own gradient, scaled by 1 / world, silently diverging
+                        raise RuntimeError("FusedAdam: a parameter's .grad no longer aliases the flat gradient buffer although a data-parallel "
+                                           "driver is attached (grad_scale != 1): use optimizer.zero_grad() (it keeps the views), not "
+                                           "model.zero_grad(set_to_none=True) / `p.grad = ...`")
                     f["g"][o:o + p.numel()].copy_(p.grad.reshape(-1))
                     p.grad = f["g"][o:o + p.numel()].view(p.shape)
             f["step"] += 1

@@ -49,7 +49,10 @@ def pmc(fetch_csv, write_csv, lines, out):
     avg = (sum((v["fetch_bytes"] + v["write_bytes"]) * v["launches"] for v in res.values()) + extra) / tot_l
     if extra:
         res["pero_splitk_reduce_k (all launches, counted into the products)"] = {"bytes_total": extra}
-    json.dump({"lines_per_gpu": int(lines), "hbm_bytes_per_launch": round(avg), "by_kernel": res,
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench   # the hash of the kernel sources this summary describes: bench.py quotes it only while they are unchanged
+    json.dump({"lines_per_gpu": int(lines), "csrc_sha256": bench.csrc_hash(), "hbm_bytes_per_launch": round(avg), "by_kernel": res,
                "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 correction); separate --pmc passes"},
               open(out, "w"), indent=1)
 
