@@ -35,9 +35,11 @@ extern "C" {
 
 /* epilogue / mode flags of pero_gemm */
 #define PERO_GEMM_RELU 1        /* C = max(C, 0) after bias/residual */
-#define PERO_GEMM_ATOMIC 2      /* f32 C only: the product is ADDED into C (split-K safe; several streams may add into one C).  With a
-                                 * `workspace` of pero_gemm_workspace_bytes() the slices of a tile are summed in slice order before the
-                                 * one add per element: bit-reproducible from run to run when C has a single writer */
+#define PERO_GEMM_ATOMIC 2      /* f32 C only: the product is ADDED into C (split-K safe).  Without a `workspace` the additions are f32
+                                 * atomics: several streams may add into one C at the same time.  WITH a `workspace` of
+                                 * pero_gemm_workspace_bytes() the slices of a tile are summed in slice order and added to C by a plain
+                                 * read-modify-write: bit-reproducible from run to run, but C must then have ONE writer at a time
+                                 * (calls that add into the same C must be ordered on one stream or by events) */
 #define PERO_GEMM_ACCUM 4       /* f32 C only: C += result (non-atomic) */
 #define PERO_GEMM_TRANS_A 8     /* A is stored [K][M] (lda = row pitch of that storage) */
 #define PERO_GEMM_TRANS_B 16    /* B is stored [K][N]; default B is stored [N][K] (Linear weight layout) */
