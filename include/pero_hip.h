@@ -64,7 +64,9 @@ int pero_abi_version(void);
 /* tuning knobs for benchmarking and tests (defaults are the measured best): "gemm_policy" (0 = auto, 1 / 4 / 7 / 20 = force one tile-kernel
  * family, table in csrc/gemm.hip), "gemm_e256_min" (192: stored products with at least that many 256x256 tiles take the eight-phase
  * kernel; 0 = never), "gemm_e_splitk_min" (4), "gemm_e_var" (diagnostic builds of that kernel), "splitk_items" (512), "splitk_xcd" (1),
- * "splitk_nearest" (0), "attn_bwd_pair" (1: the attention backward with D handed in runs as one launch, csrc/attention.hip), "splitk_workspace" (1: the split-K
+ * "splitk_nearest" (0), "attn_bwd_pair" (1: the attention backward with D handed in runs as one launch, csrc/attention.hip), "attn_pipe" (1: attention loops
+ * with software-pipelined inline-asm operand reads; 0: the compiler-scheduled loops - same bits), "attn_lh" (0; 1: S = 256 backward as one persistent workgroup
+ * per CU and (line, head) - same bits, not faster), "splitk_workspace" (1: the split-K
  * products of the eight-phase kernel leave partial tiles in the caller's `workspace`, summed in slice order by a second kernel - deterministic;
  * 0: f32 atomics even when a workspace is passed), "splitk_table" (1: unaligned slice counts hand their work items out XCD by XCD).  Process-wide; not
  * meant to be changed while products are in flight. */
