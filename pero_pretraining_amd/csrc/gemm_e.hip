@@ -45,7 +45,11 @@
 #define E_RING (2 * E_KTILE)       // 128 KiB: two K-tiles
 #define E_BIAS E_RING              // 8 x 1 KiB: each wave's copy of the tile's 256 bias floats
 #define E_LUT (E_RING + 8192 + 512)           // EP_GATE_BITS: 256 x 16 B, mask byte -> the four AND masks of its 8 bf16 columns
-#define E_LDS_BYTES (E_RING + 8192 + 512 + 4096)   // + 512 B of phase stamps (diagnostic build VAR 64) + the LUT
+#define E_XSTG (E_RING + 8192 + 512 + 4096)    // 8 x 2 KiB: each wave's staging image of the epilogue's lane transpose
+#define E_LDS_BYTES (E_XSTG + 8 * 2048)        // + 512 B of phase stamps (diagnostic build VAR 64) + the LUT + the staging
+#ifndef E_XCHG_LDS
+#define E_XCHG_LDS 1                           // 0: the lane transpose as 4 x ds_bpermute_b32 per unit (round 2)
+#endif
 
 // epilogue modes
 #define EP_PLAIN 0       // bias
@@ -324,7 +328,18 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p, int ks) {
   const unsigned gvo = (unsigned)(((128 * wr + er) * (EPI == EP_RESID ? p.ldr : p.ldg) + 64 * wc + 8 * ep) * 2);  // residual / row-dot matrix
   const unsigned mvo = (unsigned)((128 * wr + er) * p.ldg + 8 * wc);               // bit mask: 8 bytes per row and wave
   auto lane_t = [&](const unsigned x) -> unsigned { return (unsigned)__builtin_amdgcn_ds_bpermute(tsrc, (int)x); };
-  (void)cq;
+  (void)cq; (void)tsrc;
+  // The same transpose through LDS memory (E_XCHG_LDS): a unit is written as the lanes hold it (one ds_write_b128: row li, piece cq)
+  // and read back in the transposed layout (one ds_read_b128: row er, piece ep) - 13 + 4 cycles of the LDS pipeline per unit against
+  // 4 x 6 for the bpermutes (tools/probe_bperm.hip); the f32 sums of EP_RESID 2 x (13 + 4) against 8 x 6, and without their lane
+  // swaps.  A wave's LDS instructions execute in order, so the read needs no wait of its own and a slot is reused without one.
+  // Pieces are XOR-swizzled so that both directions are conflict-free (bf16: [16 rows][64 B], 2 slots; f32: [16][128 B]).
+  unsigned char* const xstg = smem + E_XSTG + wave * 2048;
+  const unsigned xw16 = (unsigned)(li * 64 + ((cq ^ ((li >> 1) & 3)) << 4));
+  const unsigned xr16 = (unsigned)(er * 64 + ((ep ^ ((er >> 1) & 3)) << 4));
+  const int xsw = (li ^ ((li >> 1) & 1)) & 7, xsr = (er ^ ((er >> 1) & 1)) & 7;
+  const unsigned xw32 = (unsigned)(li * 128), xr32 = (unsigned)(er * 128);
+  (void)xw16; (void)xr16; (void)xsw; (void)xsr; (void)xw32; (void)xr32;
   eu4v side0[8], side1[8];   // side inputs of rows 0-63 / 64-127 (EP_RESID, EP_ROWDOT: 16 B per unit)
   eu2v sm0[4], sm1[4];       // EP_GATE_BITS: the 8 mask bytes of a row (this wave's 64 columns), per row group
 
@@ -558,13 +573,23 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p, int ks) {
               if (EPI == EP_RESID) {
                 // f32 columns first (one rounding): even lane groups keep x and take the odd neighbour's x, odd ones y
                 float v[8];
+                if (E_XCHG_LDS) {
+                  // x = columns 4 lq .. + 3 (piece lq), y = columns 16 + 4 lq .. (piece 4 + lq) of the row's 32 f32; read: columns 8 ep .. + 7
+                  *(f4v*)(xstg + xw32 + ((lq ^ xsw) << 4)) = x;
+                  *(f4v*)(xstg + xw32 + (((4 + lq) ^ xsw) << 4)) = y;
+                  const f4v r0 = *(const f4v*)(xstg + xr32 + (((2 * ep) ^ xsr) << 4));
+                  const f4v r1 = *(const f4v*)(xstg + xr32 + (((2 * ep + 1) ^ xsr) << 4));
 #pragma unroll
-                for (int e = 0; e < 4; e++) {
-                  auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(x[e]), __float_as_uint(y[e]), false, false);
-                  v[e] = __uint_as_float(sw[0]); v[4 + e] = __uint_as_float(sw[1]);
+                  for (int e = 0; e < 4; e++) { v[e] = r0[e]; v[4 + e] = r1[e]; }
+                } else {
+#pragma unroll
+                  for (int e = 0; e < 4; e++) {
+                    auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(x[e]), __float_as_uint(y[e]), false, false);
+                    v[e] = __uint_as_float(sw[0]); v[4 + e] = __uint_as_float(sw[1]);
+                  }
+#pragma unroll
+                  for (int e = 0; e < 8; e++) v[e] = __uint_as_float(lane_t(__float_as_uint(v[e])));   // the f32 sums move, rounded once below
                 }
-#pragma unroll
-                for (int e = 0; e < 8; e++) v[e] = __uint_as_float(lane_t(__float_as_uint(v[e])));   // the f32 sums move, rounded once below
                 const eu4v r4 = ha ? side1[2 * i + hb] : side0[2 * i + hb];
 #pragma unroll
                 for (int e = 0; e < 4; e++) { v[2 * e] += __uint_as_float(r4[e] << 16); v[2 * e + 1] += __uint_as_float(r4[e] & 0xffff0000u); }
@@ -579,7 +604,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p, int ks) {
                 const unsigned py0 = pack2bf(ys[0], ys[1]), py1 = pack2bf(ys[2], ys[3]);
                 auto s0 = __builtin_amdgcn_permlane16_swap(px0, py0, false, false);
                 auto s1 = __builtin_amdgcn_permlane16_swap(px1, py1, false, false);
-                o[ii][hb][0] = lane_t(s0[0]); o[ii][hb][1] = lane_t(s1[0]); o[ii][hb][2] = lane_t(s0[1]); o[ii][hb][3] = lane_t(s1[1]);
+                if (E_XCHG_LDS) {
+                  *(eu4v*)(xstg + hb * 1024 + xw16) = (eu4v){s0[0], s1[0], s0[1], s1[1]};
+                  o[ii][hb] = *(const eu4v*)(xstg + hb * 1024 + xr16);
+                } else {
+                  o[ii][hb][0] = lane_t(s0[0]); o[ii][hb][1] = lane_t(s1[0]); o[ii][hb][2] = lane_t(s0[1]); o[ii][hb][3] = lane_t(s1[1]);
+                }
               }
             }
 #pragma unroll

@@ -27,7 +27,33 @@ __global__ __launch_bounds__(256) void patches_u8_k(const uint8_t* img, const in
   // LDS row pitch: an ODD number of dwords - lanes walk the image rows (h) at a fixed column, and the unpadded 384-byte pitch
   // (96 dwords) put all 40 rows on two banks (32-way conflict on every pixel read)
   const int ldsp = (((PT_TOK * P * C + 3) >> 2) | 1) << 2;
-  if ((rowbytes & 3) == 0 && (rowpitch & 3) == 0 && ((s0 * P * C) & 3) == 0 && ((uintptr_t)img & 3) == 0) {
+  // the block's mask words next to the staged pixels (read per token below: from LDS, not one dependent global load per token)
+  int* const lmask = (int*)(lds + H * ldsp);
+  if (threadIdx.x < PT_TOK) lmask[threadIdx.x] = (mask && (int)threadIdx.x < ntok) ? (mask[(long long)n * S + s0 + threadIdx.x] == 1) : 0;
+  if ((rowbytes & 15) == 0 && (rowpitch & 15) == 0 && ((s0 * P * C) & 15) == 0 && ((uintptr_t)img & 15) == 0) {
+    // 16-byte pieces, four per thread in flight (a thread's loads are issued together: the loop below them waited for each one)
+    const int rw = rowbytes >> 4, total = H * rw;
+    for (int base = threadIdx.x; base < total; base += 256 * 4) {
+      uint4 v[4];
+      int off[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int i = base + 256 * k;
+        off[k] = -1;
+        if (i < total) {
+          const int h = i / rw, b = i - h * rw;
+          v[k] = *(const uint4*)(src + h * rowpitch + 16 * b);
+          off[k] = h * ldsp + 16 * b;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        if (off[k] >= 0) {
+          unsigned* d = (unsigned*)(lds + off[k]);
+          d[0] = v[k].x; d[1] = v[k].y; d[2] = v[k].z; d[3] = v[k].w;
+        }
+    }
+  } else if ((rowbytes & 3) == 0 && (rowpitch & 3) == 0 && ((s0 * P * C) & 3) == 0 && ((uintptr_t)img & 3) == 0) {
     const int rw = rowbytes >> 2;
     int h = threadIdx.x / rw, b = threadIdx.x - h * rw;  // element (h, b), advanced by 256 per iteration without divisions
     const int dh = 256 / rw, db = 256 - dh * rw;
@@ -54,7 +80,7 @@ __global__ __launch_bounds__(256) void patches_u8_k(const uint8_t* img, const in
       const int c = ch / H, h = ch - c * H;
       const unsigned char* lrow = lds + h * ldsp + c;
       for (int tok = threadIdx.x / chp; tok < ntok; tok += tstep) {
-        const bool masked = mask && mask[(long long)n * S + s0 + tok] == 1;
+        const bool masked = lmask[tok] != 0;
         T* o = out + ((long long)n * S + s0 + tok) * ldo + (long long)ch * P;
         if (sizeof(T) == 2 && P == 8 && (ldo & 7) == 0 && (((uintptr_t)out) & 15) == 0) {
           float v[8];  // the 8 pixels of one (token, c, h) are 16 contiguous output bytes: one 16-byte store
@@ -72,7 +98,7 @@ __global__ __launch_bounds__(256) void patches_u8_k(const uint8_t* img, const in
     for (int gidx = threadIdx.x; gidx < ntok * CH; gidx += 256) {
       const int tok = gidx / CH, ch = gidx - tok * CH;
       const int c = ch / H, h = ch - c * H;
-      const bool masked = mask && mask[(long long)n * S + s0 + tok] == 1;
+      const bool masked = lmask[tok] != 0;
       T* o = out + ((long long)n * S + s0 + tok) * ldo + (long long)ch * P;
       for (int e = 0; e < P; e++) Elem<T>::st(o + e, masked ? tile[ch * P + e] : div255(lds[h * ldsp + (tok * P + e) * C + c]));
     }
@@ -139,7 +165,7 @@ extern "C" int pero_patches_from_u8(const uint8_t* images, const int64_t* mask, 
   PERO_REQUIRE(ld_out >= C * H * P, "pero_patches_from_u8: ld_out < C*H*P");
   PERO_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && P > 0 && W % P == 0 && N < 65536, "pero_patches_from_u8: bad sizes (W %% P must be 0)");
   const int S = (int)(W / P);
-  const size_t lds = (size_t)H * ((((PT_TOK * P * C + 3) >> 2) | 1) << 2);
+  const size_t lds = (size_t)H * ((((PT_TOK * P * C + 3) >> 2) | 1) << 2) + PT_TOK * sizeof(int);
   PERO_REQUIRE(lds <= 65536, "pero_patches_from_u8: H*16*P*C = %zu bytes exceeds the LDS staging budget", lds);
   dim3 grid((unsigned)((S + PT_TOK - 1) / PT_TOK), (unsigned)N), block(256);
   if (dtype == PERO_F32) hipLaunchKernelGGL((patches_u8_k<float>), grid, block, lds, (hipStream_t)stream, images, mask, tile, (float*)patches, (int)H, (int)W, (int)C, (int)P, S, (int)ld_out);
