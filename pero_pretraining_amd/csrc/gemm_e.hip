@@ -209,15 +209,25 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p, int ks) {
   const int li = lane & 15, lq = lane >> 4;
   const int kf = (li >> 2) | ((lq & 1) << 2);
   const unsigned rk0 = (unsigned)((8 * lq + (li >> 2)) * 256 + 8 * (li & 3));
+  // Transposed fragments are read by inline asm: behind an LDS-DMA hipcc (ROCm 7.2) puts `s_waitcnt vmcnt(0)` in front of every
+  // ds_read_b64_tr_b16 it can see (three per K-tile in the K-major kernels: each phase's reads then waited for the half tile
+  // issued a quarter of a K-tile earlier, i.e. for the whole memory latency, and the counted vmcnt(6) of phase 4 never mattered).
+  // The ds_read_b128 of the K-contiguous images do not get that wait.  Every read here is retired by the phase's own
+  // `s_waitcnt lgkmcnt(0)` in front of its MFMAs (E_LGKM0_F ties the fragment registers to that wait).
+  auto rd_tr = [&](const unsigned char* a) -> bf8v {
+    typedef int i2v_ __attribute__((ext_vector_type(2)));
+    i2v_ lo, hi;
+    const unsigned addr = (unsigned)(unsigned long long)LDS_PTR(const unsigned char, a);
+    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:1024" : "=&v"(lo), "=&v"(hi) : "v"(addr) : "memory");
+    return __builtin_bit_cast(bf8v, __builtin_shufflevector(lo, hi, 0, 1, 2, 3));
+  };
   auto rdA = [&](const unsigned char* base, int i, int s) -> bf8v {  // rows 64 wr + 16 i of an A half
     if (!TA) return *(const bf8v*)(base + (64 * wr + 16 * i) * 128 + (rc0 ^ (s << 6)));
-    const unsigned char* a = base + rk0 + s * 32 * 256 + (((4 * wr + i) ^ kf) << 5);
-    return lds_tr16_pair(a, a + 4 * 256);
+    return rd_tr(base + rk0 + s * 32 * 256 + (((4 * wr + i) ^ kf) << 5));
   };
   auto rdB = [&](const unsigned char* base, int j, int s) -> bf8v {  // rows 32 wc + 16 j of a B half
     if (!TB) return *(const bf8v*)(base + (32 * wc + 16 * j) * 128 + (rc0 ^ (s << 6)));
-    const unsigned char* a = base + rk0 + s * 32 * 256 + (((2 * wc + j) ^ kf) << 5);
-    return lds_tr16_pair(a, a + 4 * 256);
+    return rd_tr(base + rk0 + s * 32 * 256 + (((2 * wc + j) ^ kf) << 5));
   };
 
   f4v acc[2][2][4][2];  // [A half][B half][i][j]
@@ -246,6 +256,14 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p, int ks) {
   __builtin_amdgcn_sched_barrier(0);
 #define E_LGKM0()                                          \
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       \
+  __builtin_amdgcn_sched_barrier(0);
+// the same, with the fragments read by asm in this phase tied to the wait (an MFMA cannot move in front of it)
+#define E_LGKM0_A()                                                                                                       \
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[2][0]), \
+               "+v"(fa[2][1]), "+v"(fa[3][0]), "+v"(fa[3][1]) :: "memory");                                              \
+  __builtin_amdgcn_sched_barrier(0);
+#define E_LGKM0_B(F_)                                                                                                     \
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(F_[0][0]), "+v"(F_[0][1]), "+v"(F_[1][0]), "+v"(F_[1][1]) :: "memory");     \
   __builtin_amdgcn_sched_barrier(0);
 
   // the LDS-DMA stream: half tile `which` (0 A0, 1 A1, 2 B0, 3 B1) of K-tile u of the current tile (u >= nk: of the next
@@ -390,7 +408,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p, int ks) {
       else asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
       E_PST(1);
       E_BAR();
-      E_LGKM0();
+      E_LGKM0_B(fb0);
+      E_LGKM0_A();
       E_PST(2);
       E_MFMA(0, 0, fb0);
       E_PST(3);
@@ -401,7 +420,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p, int ks) {
       issue(t + 2, 2, kt);                                  // B0(t+2)
       E_PST(5);
       E_BAR();
-      E_LGKM0();
+      E_LGKM0_B(fb1);
       E_PST(6);
       E_MFMA(0, 1, fb1);
       E_PST(7);
@@ -412,7 +431,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p, int ks) {
       issue(t + 2, 0, kt);                                  // A0(t+2)
       E_PST(9);
       E_BAR();
-      E_LGKM0();
+      E_LGKM0_A();
       E_PST(10);
       E_MFMA(1, 1, fb1);
       E_PST(11);
