@@ -61,6 +61,22 @@
 #define EP_SPLITK 7      // f32 C += partial product of ONE k-slice (atomics): one work item (tile, k-slice) per workgroup, not persistent
 
 typedef int ei4v __attribute__((ext_vector_type(4)));
+typedef short es2v __attribute__((ext_vector_type(2)));
+typedef unsigned short eus2v __attribute__((ext_vector_type(2)));
+// two bf16 in a dword: ReLU as a signed 16-bit maximum with zero; (half != 0) per half for halves that are +0 or positive
+__device__ __forceinline__ unsigned epk_relu(unsigned v) {
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(es2v, v), (es2v){0, 0}));
+}
+// acc + a.lo * b.lo + a.hi * b.hi of two bf16 pairs (v_dot2c_f32_bf16)
+__device__ __forceinline__ float edot2(unsigned a, unsigned b, float acc) {
+  typedef __bf16 eb2v __attribute__((ext_vector_type(2)));
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(eb2v, a), __builtin_bit_cast(eb2v, b), acc, false);
+}
+__device__ __forceinline__ unsigned epk_nonzero(unsigned v) {   // (hipcc turns the vector minimum into compares and selects: asm)
+  unsigned r;
+  asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(v), "s"(0x00010001u));
+  return r;
+}
 typedef unsigned eu4v __attribute__((ext_vector_type(4)));
 typedef unsigned eu2v __attribute__((ext_vector_type(2)));
 
@@ -358,6 +374,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p, int ks) {
   const int xsw = (li ^ ((li >> 1) & 1)) & 7, xsr = (er ^ ((er >> 1) & 1)) & 7;
   const unsigned xw32 = (unsigned)(li * 128), xr32 = (unsigned)(er * 128);
   (void)xw16; (void)xr16; (void)xsw; (void)xsr; (void)xw32; (void)xr32;
+  const unsigned char* const lutp = smem + E_LUT;
+  // bf16 pairs (1, 0) and (0, 1) in registers the compiler cannot fold: as a constant operand hipcc (ROCm 7.2) prints the pair (1, 0) as the
+  // inline constant `1.0`, which v_dot2c_f32_bf16 reads as the f32 pattern 0x3f800000 = the pair (0, 1) (measured: both sums took the odd column)
+  unsigned sel_lo = 0x00003f80u, sel_hi = 0x3f800000u;
+  asm volatile("" : "+s"(sel_lo), "+s"(sel_hi));
   eu4v side0[8], side1[8];   // side inputs of rows 0-63 / 64-127 (EP_RESID, EP_ROWDOT: 16 B per unit)
   eu2v sm0[4], sm1[4];       // EP_GATE_BITS: the 8 mask bytes of a row (this wave's 64 columns), per row group
 
@@ -581,11 +602,18 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p, int ks) {
 #pragma unroll
         for (int ib = 0; ib < 4; ib += NI) {
           eu4v o[NI][2];
+          eu4v kp[NI][2];   // EP_GATE_BITS: the AND masks of the unit's 8 columns, requested with the staging reads (not in front of their use)
+          (void)kp;
 #pragma unroll
           for (int ii = 0; ii < NI; ii++)
 #pragma unroll
             for (int hb = 0; hb < 2; hb++) {
               const int i = ib + ii;
+              if (EPI == EP_GATE_BITS) {
+                const eu2v mm = ha ? sm1[i] : sm0[i];
+                const unsigned byte = __builtin_amdgcn_ubfe(hb ? mm[1] : mm[0], 8u * (unsigned)ep, 8u);
+                kp[ii][hb] = *(const eu4v*)(lutp + (byte << 4));
+              }
               // (alpha = 1: the other kernels' acc * alpha + bias, bit for bit; the modes that never take a bias skip the add of zero)
               const f4v x = EPI <= EP_RELU_BITS ? acc[ha][hb][i][0] + bx[hb][0] : acc[ha][hb][i][0];
               const f4v y = EPI <= EP_RELU_BITS ? acc[ha][hb][i][1] + bx[hb][1] : acc[ha][hb][i][1];
@@ -614,13 +642,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p, int ks) {
                 for (int e = 0; e < 4; e++) { v[2 * e] += __uint_as_float(r4[e] << 16); v[2 * e + 1] += __uint_as_float(r4[e] & 0xffff0000u); }
                 o[ii][hb][0] = pack2bf(v[0], v[1]); o[ii][hb][1] = pack2bf(v[2], v[3]); o[ii][hb][2] = pack2bf(v[4], v[5]); o[ii][hb][3] = pack2bf(v[6], v[7]);
               } else {
-                float xs[4] = {x[0], x[1], x[2], x[3]}, ys[4] = {y[0], y[1], y[2], y[3]};
+                unsigned px0 = pack2bf(x[0], x[1]), px1 = pack2bf(x[2], x[3]);
+                unsigned py0 = pack2bf(y[0], y[1]), py1 = pack2bf(y[2], y[3]);
                 if (EPI == EP_RELU || EPI == EP_RELU_BITS) {
-#pragma unroll
-                  for (int e = 0; e < 4; e++) { xs[e] = fmaxf(xs[e], 0.f); ys[e] = fmaxf(ys[e], 0.f); }
+                  // ReLU on the ROUNDED pairs: one v_pk_max_i16 per dword instead of two v_max_f32 (rounding keeps the sign, so
+                  // max(round(x), 0) == round(max(x, 0)); a negative value or -0 is a negative int16 and becomes +0)
+                  px0 = epk_relu(px0); px1 = epk_relu(px1); py0 = epk_relu(py0); py1 = epk_relu(py1);
                 }
-                const unsigned px0 = pack2bf(xs[0], xs[1]), px1 = pack2bf(xs[2], xs[3]);
-                const unsigned py0 = pack2bf(ys[0], ys[1]), py1 = pack2bf(ys[2], ys[3]);
                 auto s0 = __builtin_amdgcn_permlane16_swap(px0, py0, false, false);
                 auto s1 = __builtin_amdgcn_permlane16_swap(px1, py1, false, false);
                 if (E_XCHG_LDS) {
@@ -645,29 +673,26 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p, int ks) {
                 unsigned z = 0;
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                  const unsigned m = (((ou[k] & 0x7fff7fffu) + 0x7fff7fffu) & 0x80008000u) >> 15;  // bit 0: low half > 0, bit 16: high half
+                  const unsigned m = epk_nonzero(ou[k]);  // bit 0: low half > 0, bit 16: high half (one v_pk_min_u16: the halves are >= +0)
                   z |= m << (2 * k);
                 }
                 const unsigned byte = (z & 0x55u) | ((z >> 15) & 0xaau);
                 if (hb == 0) mL = byte << (8 * ep); else mH = byte << (8 * ep);
               }
               if (EPI == EP_GATE_BITS) {
-                const eu2v mm = ha ? sm1[i] : sm0[i];
-                const unsigned byte = ((hb ? mm[1] : mm[0]) >> (8 * ep)) & 0xffu;
-                const eu4v keep = *(const eu4v*)(smem + E_LUT + byte * 16);
+                // column sums always (no branch per dword on the runtime flag; only the final atomic is conditional): one
+                // v_dot2c_f32_bf16 per column pair and half, (x, y) . (1, 0) and (x, y) . (0, 1) - exact products, exact sums with zero
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                  ou[k] &= keep[k];
-                  if (colsum) { cs[hb][2 * k] += __uint_as_float(ou[k] << 16); cs[hb][2 * k + 1] += __uint_as_float(ou[k] & 0xffff0000u); }
+                  ou[k] &= kp[ii][hb][k];
+                  cs[hb][2 * k] = edot2(ou[k], sel_lo, cs[hb][2 * k]);
+                  cs[hb][2 * k + 1] = edot2(ou[k], sel_hi, cs[hb][2 * k + 1]);
                 }
               }
               if (EPI == EP_ROWDOT) {
                 const eu4v g4 = ha ? side1[2 * i + hb] : side0[2 * i + hb];
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                  rd[i] += __uint_as_float(ou[k] << 16) * __uint_as_float(g4[k] << 16);
-                  rd[i] += __uint_as_float(ou[k] & 0xffff0000u) * __uint_as_float(g4[k] & 0xffff0000u);
-                }
+                for (int k = 0; k < 4; k++) rd[i] = edot2(ou[k], g4[k], rd[i]);   // one v_dot2c_f32_bf16 instead of 4 unpacks, 2 multiplies, 2 adds
               }
               if (VAR & 4) {  // ablation: no stores (the values stay live)
                 asm volatile("" :: "v"(ou[0]), "v"(ou[1]), "v"(ou[2]), "v"(ou[3]));
@@ -686,7 +711,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p, int ks) {
               mH |= (unsigned)__builtin_amdgcn_mov_dpp((int)mH, 0x4E, 0xf, 0xf, false);
               const eu2v mo = {mL, mH};
               const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc((unsigned char*)p.gate + tm0 * p.ldg + (tn0 >> 3), 0, (int)(256 * p.ldg), 0x00020000);
-              // all four store them (same address, same data): one instruction, no branch
+              // all four store them (same address, same data): one instruction, no branch (storing from the quad's first lane only
+              // measured no faster)
               __builtin_amdgcn_raw_buffer_store_b64(mo, mrs, mvo, (64 * ha + 16 * i) * (int)p.ldg, 0);
             }
             if (EPI == EP_ROWDOT) {
