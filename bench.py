@@ -340,7 +340,7 @@ def main():
     ap.add_argument("--steps", type=int, default=100)     # warm-up 20 steps, time >= 100 steps, median of 5 repeats
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--repeats", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("PERO_BENCH_BATCH", 1024)), help="lines per GPU")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("PERO_BENCH_BATCH", 1536)), help="lines per GPU")
     ap.add_argument("--no-side-stream", action="store_true", help="weight gradients on the main stream (clean per-kernel profiles)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -15,7 +15,8 @@ model, opt_, sched, trainer = bench.build(dev, True)
 batches = bench.synthetic(0, 1024, dev)
 def step(i):
     sched.update_learning_rate(i)
-    return trainer.train_step_prepared(*batches[i % 2])
+    b = batches[i % 2]
+    return trainer.train_step_prepared(b["images"], b["labels_dev"], b["mask_dev"])
 for i in range(4): step(i)
 torch.cuda.synchronize()
 for rep in range(3):
