@@ -56,7 +56,9 @@ def linear_fwd(x, w, b, dtype, residual=None, relu=False, out_dtype=None, relu_b
 
 FUSE_ROWDOT = True     # attention backward's D = rowsum(dO * O) from the epilogue of the out-projection's dX product
 FUSE_BIAS_GRAD = True  # bias gradients that are column sums of a dX product's output come out of that product's epilogue
-SIDE_STREAM_DW = True  # weight / bias gradients on a second HIP stream (they are off the backward critical path)
+SIDE_STREAM_DW = False  # weight / bias gradients on a second HIP stream (they are off the backward critical path).  Off since round 3: every
+                        # product is a whole-chip kernel now (persistent dX tiles, 256 split-K work items), two of them side by side only
+                        # share the CUs - B = 1536 step 115.6 ms with, 114.6 ms without (same box, interleaved); rounds 1-2 gained 0.5-1 ms
 SIDE_STREAMS = 2       # side streams used round-robin (the library's split-K aims at 512 work items per product)
 _side_streams = {}
 
