@@ -387,14 +387,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.plumbing_test:
         return plumbing_test(args, world, rank, emit)
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # PERO_BENCH_REHEARSE_GLOO=1: rehearsal of the world > 1 code paths on a box with fewer GPUs than ranks - the ranks share the
+    # devices that exist and exchange over gloo (RCCL needs one device per rank); the timings mean nothing and the line says so
+    rehearse = os.environ.get("PERO_BENCH_REHEARSE_GLOO") == "1"
+    dev_index = local_rank % max(1, torch.cuda.device_count()) if rehearse else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     backend = None
     if "RANK" in os.environ:  # launched by torch.distributed.run (also with one rank: same code path)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", device_id=device)
-        backend = dist.get_backend()
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
+        backend = dist.get_backend() + (" (REHEARSAL: ranks share devices, timings not meaningful)" if rehearse else "")
 
     from pero_pretraining_amd import functional as F
     from pero_pretraining_amd.parallel import DataParallel
