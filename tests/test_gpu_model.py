@@ -281,3 +281,35 @@ def test_hip_graph_step_equals_eager_step(golden):
             d = v.shape[0] // 3
             v, w = np.delete(v, np.s_[d:2 * d]), np.delete(w, np.s_[d:2 * d])
         assert np.abs(v - w).max() <= 1e-4, k
+
+
+def test_weight_gradients_on_a_side_stream_give_the_same_gradients(golden):
+    """functional.SIDE_STREAM_DW (off by default since round 3: two whole-chip kernels side by side only share the CUs): the weight / bias
+    gradients of the backward pass on a second HIP stream - same loss, same gradients (the option stays covered)."""
+    import copy
+    from pero_pretraining_amd import functional as F
+    torch.manual_seed(11)
+    base = build_tiny().train()
+    rng = np.random.default_rng(12)
+    images = torch.from_numpy(rng.integers(0, 256, (6, 40, 256, 3), dtype=np.uint8)).cuda()
+    labels = torch.from_numpy(rng.integers(0, 96, (6, 32)).astype(np.int64)).cuda()
+    mask = (rng.random((6, 32)) < 0.25).astype(np.int64)
+    mask[0, 0] = 1
+    offs = rng.integers(0, 4096 - 32, 6)
+    res = {}
+    assert F.SIDE_STREAM_DW is False
+    try:
+        for side in (False, True):
+            F.SIDE_STREAM_DW = side
+            model = copy.deepcopy(base)
+            model.backbone.set_offsets(offs)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                out = model(images, labels, mask)
+            out["loss"].backward()
+            torch.cuda.synchronize()
+            res[side] = (float(out["loss"]), {k: p.grad.detach().clone() for k, p in model.named_parameters()})
+    finally:
+        F.SIDE_STREAM_DW = False
+    assert res[True][0] == res[False][0]
+    for k, g in res[False][1].items():
+        assert (res[True][1][k] - g).abs().max() <= 1e-5 * max(float(g.abs().max()), 1e-6), k
