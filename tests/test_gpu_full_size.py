@@ -117,9 +117,9 @@ def test_config2_topk_error_counters_monotone(cfg2):
     assert c[0] == int(mask.sum()) and c[1] >= c[2] >= c[3] >= c[4] > 0
 
 
-@pytest.mark.parametrize("B,relu_bits", [(256, False), (512, True), (1024, True)])
+@pytest.mark.parametrize("B,relu_bits", [(256, False), (512, True), (1024, True), (2048, True)])
 def test_bench_scale_step_equals_the_weighted_sum_of_its_sub_batches(B, relu_bits, monkeypatch):
-    """B = 256 / 512 / 1024 lines (1024 = bench.py's default; M = 65 536 ... 262 144 token rows: the persistent 256x256x64 products with every epilogue mode, the bit-mask ReLU
+    """B = 256 / 512 / 1024 / 2048 lines (2048 = bench.py's default since round 3, 1024 before; M = 65 536 ... 524 288 token rows: the persistent 256x256x64 products with every epilogue mode, the bit-mask ReLU
     gate, transposed-weight input gradients, long split-K weight gradients) against the SAME lines in 16-line sub-batches
     (the 256x128x32 / 128x128 kernels that the oracle tests pin).  Lines are independent, so the logits must agree row by
     row, the loss is the masked-count-weighted mean of the sub-batch losses and every gradient the same weighted sum."""
