@@ -72,6 +72,15 @@ def test_epilogues_match_the_other_tile_kernel_bit_for_bit(e256, M, N, K):
     gr = ops.gemm(x, w, gate=h)
     _setpol(20)
     assert torch.equal(gd, gr) and torch.equal(gd, ops.gemm(x, w, relu_bits=bits))
+    # ... and WITH an input bias (round-2 advisor finding: the e256 gate epilogue has no input-bias path and once dropped it silently; such a
+    # product now goes to the 256x128x32 kernel at every tile count): the same bits under both policies, and the bias is really in them
+    gb = ops.gemm(x, w, bias=bias, relu_bits=bits)
+    _setpol(7)
+    gb7 = ops.gemm(x, w, bias=bias, gate=h)
+    _setpol(20)
+    assert torch.equal(gb, gb7)
+    keep = h.float() > 0
+    assert float(((gb.float() - (ref + bias)) * keep).abs().max()) <= 2e-2 * float(ref.abs().max()) and float((gb.float() * ~keep).abs().max()) == 0.0
     want_cs = 3.0 + gd.float().sum(0)
     assert float((cs - want_cs).abs().max()) <= 1e-3 * max(1.0, float(want_cs.abs().max()))
     # row dots
