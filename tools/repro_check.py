@@ -13,7 +13,8 @@ for run in range(2):
     for i in range(4):
         sched.update_learning_rate(i + 1)
         torch.manual_seed(100 + i)
-        losses.append(float(trainer.train_step_prepared(*batches[i % 2])))
+        b = batches[i % 2]
+        losses.append(float(trainer.train_step_prepared(b["images"], b["labels_dev"], b["mask_dev"])))
     torch.cuda.synchronize()
     cs = float(sum(p.double().sum() for p in model.parameters()))
     res.append((losses, cs))
