@@ -379,6 +379,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p, int ks) {
   // inline constant `1.0`, which v_dot2c_f32_bf16 reads as the f32 pattern 0x3f800000 = the pair (0, 1) (measured: both sums took the odd column)
   unsigned sel_lo = 0x00003f80u, sel_hi = 0x3f800000u;
   asm volatile("" : "+s"(sel_lo), "+s"(sel_hi));
+  float cs_run = 0.f;        // EP_GATE_BITS + column sums: the wave's running sums of its current N-tile (see the epilogue)
+  long long cs_tn0 = -1;
   eu4v side0[8], side1[8];   // side inputs of rows 0-63 / 64-127 (EP_RESID, EP_ROWDOT: 16 B per unit)
   eu2v sm0[4], sm1[4];       // EP_GATE_BITS: the 8 mask bytes of a row (this wave's 64 columns), per row group
 
@@ -472,7 +474,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p, int ks) {
       // normally the three half tiles of t+2; in a tile's first K-tile also the previous epilogue (side loads of rows 64-127,
       // stores) and the bias row; in its last K-tile the side loads issued just above.
       if (!last && t == 0 && first) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");  // + the bias row
-      else if (!last && t == 0 && !first && colsum) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(6 + 1 + CN::L1 + 2 * CN::S_HALF + 1) : "memory");  // + the column-sum atomic
+      // (the column-sum atomic of EP_GATE_BITS leaves only when the workgroup's N-tile changes: on that one tile the count below asks for
+      //  one operation more than needed to have retired - never for one less)
       else if (!last && t == 0 && !first) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(6 + 1 + CN::L1 + 2 * CN::S_HALF) : "memory");
       else if (CN::L0 && last) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(6 + CN::L0) : "memory");
       else if (EPI == EP_SPLITK && t + 2 >= nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stream has ended
@@ -731,26 +734,43 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p, int ks) {
         // rows; a halving butterfly over the 16 row indices of the wave (lane bits 2-5: xor 32, 16, 8, 4; each step a lane keeps half of
         // its values and adds the partner's copy of them - 15 exchanges instead of 64) leaves the total of value `er` on the lane,
         // and ONE atomic instruction with all 64 lanes adds the wave's 64 column sums
+        // The exchanges stay in the vector ALU (round 3; as 15 ds_bpermute_b32 the four dependent LDS round trips at the very end of the
+        // epilogue were ~1 us per tile = 6 % of the gated product): lanes 32 / 16 apart trade by v_permlane32_swap / v_permlane16_swap - the
+        // swap of (a, b) followed by a + b IS "keep one, add the partner's copy of it" for both partners at once - lanes 8 / 4 apart by DPP
+        // row rotations / shifts; a + partner(a) is the same on both partners, each then keeps the sum that is its to keep.
         float w8[8], w4[4], w2[2];
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-          const float a = cs[0][j], b2 = cs[1][j];
-          const float send = (er & 8) ? a : b2, keepv = (er & 8) ? b2 : a;
-          w8[j] = keepv + __shfl_xor(send, 32, 64);
+          auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(cs[0][j]), __float_as_uint(cs[1][j]), false, false);
+          w8[j] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);      // lanes 0-31 (er & 8 == 0): cs[0][j] of both; lanes 32-63: cs[1][j] of both
         }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-          const float send = (er & 4) ? w8[j] : w8[j + 4], keepv = (er & 4) ? w8[j + 4] : w8[j];
-          w4[j] = keepv + __shfl_xor(send, 16, 64);
+          auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(w8[j]), __float_as_uint(w8[j + 4]), false, false);
+          w4[j] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);      // er & 4 == 0: w8[j] of both; else w8[j + 4] of both
         }
 #pragma unroll
         for (int j = 0; j < 2; j++) {
-          const float send = (er & 2) ? w4[j] : w4[j + 2], keepv = (er & 2) ? w4[j + 2] : w4[j];
-          w2[j] = keepv + __shfl_xor(send, 8, 64);
+          const float s0 = w4[j] + __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(w4[j]), 0x128, 0xf, 0xf, false));          // row_ror:8 = lane ^ 8
+          const float s1 = w4[j + 2] + __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(w4[j + 2]), 0x128, 0xf, 0xf, false));
+          w2[j] = (er & 2) ? s1 : s0;
         }
-        const float send = (er & 1) ? w2[0] : w2[1], keepv = (er & 1) ? w2[1] : w2[0];
-        const float tot = keepv + __shfl_xor(send, 4, 64);     // value index er = 8 * hb + e, of the lane's piece ep
-        atomicAdd((float*)p.bias + tn0 + 64 * wc + 32 * (er >> 3) + 8 * ep + (er & 7), tot);
+        // lane ^ 4 inside a row of 16: lanes with bit 2 clear take lane + 4 (row_shl:4 into banks 0, 2), the others lane - 4 (row_shr:4 into banks 1, 3)
+        auto x4 = [&](float v) -> float {
+          int r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x104, 0xf, 0x5, false);
+          r = __builtin_amdgcn_update_dpp(r, __float_as_int(v), 0x114, 0xf, 0xa, false);
+          return __int_as_float(r);
+        };
+        const float t0 = w2[0] + x4(w2[0]), t1 = w2[1] + x4(w2[1]);
+        const float tot = (er & 1) ? t1 : t0;     // value index er = 8 * hb + e, of the lane's piece ep
+        // A persistent workgroup keeps ONE N-tile while ntn divides its stride (ntn = 8 at N = 2048: always): the wave's 64 column sums run
+        // on in ONE register over its tiles and leave by one atomic when the N-tile changes or the kernel ends (per tile: 131 072
+        // wave-atomics per 2048-line launch onto 2048 addresses, each of them in the in-order vmcnt queue for ~3 k cycles)
+        if (tn0 != cs_tn0) {
+          if (cs_tn0 >= 0) atomicAdd((float*)p.bias + cs_tn0 + 64 * wc + 32 * (er >> 3) + 8 * ep + (er & 7), cs_run);
+          cs_run = 0.f; cs_tn0 = tn0;
+        }
+        cs_run += tot;
       }
     }
     E_STAMP(2);
@@ -769,6 +789,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p, int ks) {
     ((unsigned long long*)p.gate)[(VAR & 8 ? (size_t)gridDim.x * 2 * 64 * 4 : 0) + ((size_t)blockIdx.x * 2 + wr) * 32 + lane] = ((unsigned long long*)(smem + E_RING + 8192))[wr * 32 + lane];
   if ((VAR & 128) && wc == 0 && lane < 32)
     ((unsigned long long*)p.gate)[((size_t)blockIdx.x * 2 + wr) * 32 + lane] = ((unsigned long long*)(smem + E_RING + 8192))[wr * 32 + lane];
+  if (EPI == EP_GATE_BITS && colsum && cs_tn0 >= 0) atomicAdd((float*)p.bias + cs_tn0 + 64 * wc + 32 * (lane >> 5) + 8 * (lane & 3) + ((lane >> 2) & 7), cs_run);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last tile's surplus prefetches land before the LDS is released
   if ((VAR & 16) && wr == 0) { E_BAR(); }  // balance the stagger barrier (otherwise the last epilogue's extra barrier has done it)
 #undef E_RD_A
