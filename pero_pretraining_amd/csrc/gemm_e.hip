@@ -140,7 +140,10 @@ template <int EPI> struct ECnt {
   // next tile's K-tile 1], side loads of rows 64-127, then the stores / atomics of the two halves
   static constexpr int L0 = (EPI == EP_RESID || EPI == EP_ROWDOT) ? 8 : 0;  // (EP_GATE_BITS: its 8 mask loads go out in phase 1 of the last K-tile, ahead of A1(t+1): every later wait retires them)
   static constexpr int L1 = L0;
-  static constexpr int S_HALF = 8 + (EPI == EP_RELU_BITS ? 4 : 0) + (EPI == EP_ROWDOT ? 4 : 0);
+#ifndef E_ABL
+#define E_ABL 0    // timing-only ablation builds (results wrong by design): 1 no bit-mask stores (ReLU + bits), 2 no bit-mask loads (gate)
+#endif
+  static constexpr int S_HALF = 8 + ((EPI == EP_RELU_BITS && !(E_ABL & 1)) ? 4 : 0) + (EPI == EP_ROWDOT ? 4 : 0);
 };
 
 // Work-item order for split-K slice counts that are no multiple of 8 (e.g. 12 tiles x 21 slices).  Workgroup T runs on XCD T & 7;
@@ -422,8 +425,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p, int ks) {
 #pragma unroll
         for (int i = 0; i < 4; i++) {
           const int so0 = 16 * i * spitch, so1 = (64 + 16 * i) * spitch;
+          if (E_ABL & 2) { sm0[i] = (eu2v){0xffffffffu, 0xffffffffu}; sm1[i] = sm0[i]; asm volatile("" : "+v"(sm0[i]), "+v"(sm1[i])); }
+          else {
           E_BLOAD8(sm0[i], mvo, srs, so0, 0);
           E_BLOAD8(sm1[i], mvo, srs, so1, 0);
+          }
         }
       }
       if (last || t > 0) issue(t + 1, 1, kn);                       // A1(t+1)  (a tile's A1(1) went out ahead of the previous epilogue)
@@ -716,7 +722,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p, int ks) {
               const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc((unsigned char*)p.gate + tm0 * p.ldg + (tn0 >> 3), 0, (int)(256 * p.ldg), 0x00020000);
               // all four store them (same address, same data): one instruction, no branch (storing from the quad's first lane only
               // measured no faster)
-              __builtin_amdgcn_raw_buffer_store_b64(mo, mrs, mvo, (64 * ha + 16 * i) * (int)p.ldg, 0);
+              if (E_ABL & 1) asm volatile("" :: "v"(mo[0]), "v"(mo[1]));
+              else __builtin_amdgcn_raw_buffer_store_b64(mo, mrs, mvo, (64 * ha + 16 * i) * (int)p.ldg, 0);
             }
             if (EPI == EP_ROWDOT) {
               // sum over the four lanes of a row (one quad), then its first lane adds into [m][n / 128] (two waves per 128-column block)
