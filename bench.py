@@ -445,7 +445,7 @@ def main():
         for i in range(args.warmup):
             step(i)
         elapsed, repeats, loss = timer.median(step, args.steps, args.repeats, first=args.warmup)
-        final_loss = float(loss)
+        final_loss = float(loss.detach()) if hasattr(loss, "detach") else float(loss)
         lines_per_s = world * args.batch * args.steps / elapsed
         step_flops = flops_per_line()
         exec_flops = flops_per_line(masked_frac=0.15) if (args.head_backward == "masked" and not args.masked_head) else step_flops
