@@ -140,6 +140,10 @@ template <int EPI> struct ECnt {
   // next tile's K-tile 1], side loads of rows 64-127, then the stores / atomics of the two halves
   static constexpr int L0 = (EPI == EP_RESID || EPI == EP_ROWDOT) ? 8 : 0;  // (EP_GATE_BITS: its 8 mask loads go out in phase 1 of the last K-tile, ahead of A1(t+1): every later wait retires them)
   static constexpr int L1 = L0;
+#ifndef E_DUP
+#define E_DUP 0    // timing probe (-DE_DUP=1): every B0 half tile is requested twice - ten LDS-DMA instructions per wave and K-tile instead of eight, the
+#endif             // load of the row-complete 128 x 512 tile of DESIGN.md "what comes next"; every counted wait leaves two more operations in flight
+#define E_DX (2 * E_DUP)
 #ifndef E_ABL
 #define E_ABL 0    // timing-only ablation builds (results wrong by design): 1 no bit-mask stores (ReLU + bits), 2 no bit-mask loads (gate)
 #endif
@@ -300,6 +304,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p, int ks) {
     unsigned char* dst = ktbase + which * E_HALF + wave * 1024;
     if (which < 2) eglds2((nx ? nA : cA) + uu * sa.ktile + which * sa.half, sa.piece, offA, dst);
     else eglds2((nx ? nB : cB) + uu * sb.ktile + (which - 2) * sb.half, sb.piece, offB, dst);
+    if (E_DUP && which == 2) eglds2((nx ? nB : cB) + uu * sb.ktile + (which - 2) * sb.half, sb.piece, offB, dst);   // timing probe: the same half tile again
   };
   const bool use_bias = (EPI <= EP_RELU_BITS) && p.bias;
   unsigned char* const biasl = smem + E_BIAS + wave * 1024;
@@ -331,6 +336,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p, int ks) {
   // ---- prologue: K-tile 0 and all of K-tile 1 (a tile's A1(1) is always issued ahead of its first K-tile)
   issue(0, 2, smem); issue(0, 0, smem); issue(0, 3, smem); issue(0, 1, smem);
   issue(1, 2, smem + E_KTILE); issue(1, 0, smem + E_KTILE); issue(1, 3, smem + E_KTILE); issue(1, 1, smem + E_KTILE);
+  if (E_DUP) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else
   asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   E_BAR();
   if (wr == 1) { E_BAR(); }  // the stagger: waves 4-7 run one barrier behind
@@ -479,13 +485,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p, int ks) {
       // K-tile t+1 has landed (this wave's pieces).  What was issued after its last half tile A1(t+1) stays in flight:
       // normally the three half tiles of t+2; in a tile's first K-tile also the previous epilogue (side loads of rows 64-127,
       // stores) and the bias row; in its last K-tile the side loads issued just above.
-      if (!last && t == 0 && first) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");  // + the bias row
+      if (!last && t == 0 && first) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(7 + E_DX) : "memory");  // + the bias row
       // (the column-sum atomic of EP_GATE_BITS leaves only when the workgroup's N-tile changes: on that one tile the count below asks for
       //  one operation more than needed to have retired - never for one less)
-      else if (!last && t == 0 && !first) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(6 + 1 + CN::L1 + 2 * CN::S_HALF) : "memory");
-      else if (CN::L0 && last) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(6 + CN::L0) : "memory");
+      else if (!last && t == 0 && !first) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(6 + E_DX + 1 + CN::L1 + 2 * CN::S_HALF) : "memory");
+      else if (CN::L0 && last) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(6 + E_DX + CN::L0) : "memory");
       else if (EPI == EP_SPLITK && t + 2 >= nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stream has ended
-      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" :: "i"(6 + E_DX) : "memory");
       E_PST(13);
       if ((VAR & 128) && last && tix == 2) { E_KST(nk + 5); }
       E_BAR();
