@@ -371,6 +371,7 @@ extern int g_attn_pipe;
 extern int g_attn_lh;
 extern int g_gemm_splitk_ws;          // gemm_e.hip
 extern int g_gemm_splitk_table;
+extern int g_gemm_nw;
 static int g_gemm_policy = 0;         // 0 = auto, 1 = 128x128x64 persistent kernel (this file), 4 = gemm_bf16_o128, 7 = gemm_bf16_r256, 20 = gemm_bf16_e256
 static int g_gemm_e256_min = 192;     // auto: stored products with at least this many 256x256 tiles take the eight-phase kernel (0 = never)
 static int g_gemm_e_splitk_min = 4;   // ... and split-K products (reduction >= 32768 rows) with at least this many output tiles
@@ -385,6 +386,7 @@ extern "C" int pero_set_option(const char* name, int value) {
   if (name && !strcmp(name, "attn_lh")) { g_attn_lh = value; return PERO_OK; }
   if (name && !strcmp(name, "splitk_workspace")) { g_gemm_splitk_ws = value; return PERO_OK; }
   if (name && !strcmp(name, "splitk_table")) { g_gemm_splitk_table = value; return PERO_OK; }
+  if (name && !strcmp(name, "gemm_nw")) { g_gemm_nw = value; return PERO_OK; }
   if (name && !strcmp(name, "gemm_e256_min")) { g_gemm_e256_min = value; return PERO_OK; }
   if (name && !strcmp(name, "gemm_e_splitk_min")) { g_gemm_e_splitk_min = value; return PERO_OK; }
   if (name && !strcmp(name, "splitk_xcd")) { g_pero_splitk_xcd = value; return PERO_OK; }
@@ -492,6 +494,11 @@ static int gemm_dispatch(const void* A, const void* B, void* C, const float* bia
     if (atomic && out_dtype == PERO_F32 && batch == 1 && splitk_takes_e256(M, N, K, flags) &&
         pero_launch_gemm_e256(p, batch, k_split_req, ta, tb, true, st, -1, workspace, workspace_bytes)) {
       PERO_CHECK_LAUNCH("pero_gemm(e256 split-K)");
+      return PERO_OK;
+    }
+    // the row-complete 128 x 512 tile (opt-in): N = 512 stored products with the plain / residual epilogue
+    if (!atomic && g_gemm_nw && !want_cs && out_dtype == PERO_BF16 && pero_launch_gemm_n512(p, batch, ta, tb, false, st)) {
+      PERO_CHECK_LAUNCH("pero_gemm(n512)");
       return PERO_OK;
     }
     // ... and stored bf16 products with every fused epilogue

@@ -813,6 +813,339 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p, int ks) {
 #undef E_STAMP
 }
 
+// =====================================================================================================================================
+// ROW-COMPLETE tile for the N = 512 products (DESIGN.md "what comes next"; opt-in: pero_set_option("gemm_nw", 1)): one workgroup owns 128 rows x
+// ALL 512 columns, so that an epilogue can see whole rows (the residual LayerNorm of the out-projection / linear2 products, the LayerNorm
+// backward behind linear1's / in_proj's input gradients).  The eight-phase compute code of gemm_bf16_e256 with another operand assignment:
+//  * the two wave GROUPS take the two N-tiles of the same 128 rows: wave (g, wc) = all 128 rows (the two 64-row parts of ONE A half tile, which
+//    both groups read: part 0 in phase 1, part 1 in phase 3) x the 32 wc columns of each half of N-tile g.  The same 128 x 64 outputs, the same
+//    fragment reads and MFMAs per wave and K-tile as in the 256 x 256 tile.
+//  * a K-tile is FIVE half tiles (A, B00, B10, B01, B11; Bgh = half h of N-tile g): A - the HBM stream - has its own ring of three slots, the four
+//    B half tiles - the 512-row weight matrix, which every workgroup streams from L2 - roll through six: nine slots = 144 KiB + 16 KiB of epilogue
+//    staging = all of the CU's LDS; the bias comes by side loads.  A slot is restaged two phases after its last read (B00 / B10: one phase,
+//    their reads are retired by the lgkmcnt(8) in front of phase 1's first barrier):
+//        phase 1 of K-tile t: A(t+2) -> A(t-1)'s slot          phase 2: B01(t+1), B11(t+1) -> the slots of B00(t), B10(t)
+//        phase 4:             B00(t+2), B10(t+2) -> the slots of B01(t), B11(t)
+//    (slots: A(t) = t % 3; with gb = 4 t % 6: B00 gb, B10 gb + 1, B01 gb + 2, B11 gb + 3, all mod 6 - every index has period three K-tiles).
+//  * counted waits, two per K-tile: W2 in phase 1 (B01 / B11 of THIS K-tile, read from phase 2 on: newer are B00 / B10 of t + 1 and A(t+2) = 6
+//    instructions) and W1 in phase 4 (A, B00, B10 of t + 1: newer are A(t+2), B01 / B11(t+1), B00 / B10(t+2) = 10); in a tile's first K-tile the
+//    previous epilogue's side loads and stores, in its last the side loads of its own epilogue are counted out (constants at the waits).
+// Epilogue: gemm_bf16_e256's plain / residual epilogue with `128 wr` gone from the row offsets and `256 wr` added to the columns.
+#define N_BM 128
+#define N_ASLOTS 3
+#define N_BSLOTS 6
+#define N_RING ((N_ASLOTS + N_BSLOTS) * E_HALF)     // 147 456
+#define N_XSTG N_RING                                // 8 x 2 KiB: each wave's staging image of the epilogue's lane transpose
+#define N_LDS_BYTES (N_XSTG + 8 * 2048)              // 163 840 = the CU's 160 KiB
+
+template <int EPI, bool BIAS>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_n512(GemmP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  static_assert(EPI == EP_PLAIN || EPI == EP_RESID, "the row-complete tile has the plain and the residual epilogue");
+  constexpr int LB = BIAS ? 4 : 0;                        // bias side loads (16 B per lane each)
+  constexpr int L0 = LB + (EPI == EP_RESID ? 8 : 0);      // side loads issued in phase 4 of the last K-tile: bias + residual rows 0-63
+  constexpr int L1 = EPI == EP_RESID ? 8 : 0;             // residual rows 64-127, issued at the epilogue's start
+  constexpr int SH = 8;                                   // stores per half of the epilogue
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;                // wr: N-tile (columns 256 wr ...), wc: its 64-column strip
+  const int nt = (int)(p.M / N_BM);
+  const int G = gridDim.x;                                // multiple of 8
+  const int q8 = nt >> 3, r8 = nt & 7;
+  const int nk = (int)(p.K / E_BK);                       // >= 3 (launcher)
+  const unsigned offA = elane_off<false, true>(p.lda, tid), offB = elane_off<false, false>(p.ldb, tid);
+  auto tile_of = [&](int T) -> long long {
+    const int xcd = T & 7, loc = T >> 3;
+    const int id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
+    return (long long)id * N_BM;
+  };
+  int T = blockIdx.x;
+  if (T >= nt) return;
+  long long tm0 = tile_of(T);
+  bool has_next = T + G < nt;
+  long long nm0 = tile_of(has_next ? T + G : T);
+
+  const unsigned rc0 = (unsigned)((lane & 15) * 128 + ((((lane >> 4)) ^ (lane & 7)) << 4));
+  const int li = lane & 15, lq = lane >> 4;
+  auto rdA = [&](const unsigned char* base, int ha, int i, int s) -> bf8v {   // rows 64 ha + 16 i of the A half tile
+    return *(const bf8v*)(base + (64 * ha + 16 * i) * 128 + (rc0 ^ (s << 6)));
+  };
+  auto rdB = [&](const unsigned char* base, int j, int s) -> bf8v {           // rows 32 wc + 16 j of a B half tile
+    return *(const bf8v*)(base + (32 * wc + 16 * j) * 128 + (rc0 ^ (s << 6)));
+  };
+  f4v acc[2][2][4][2];  // [A part][B half][i][j]
+  bf8v fa[4][2], fb0[2][2], fb1[2][2];
+#define N_RD_A(HA_)                                                           \
+  _Pragma("unroll") for (int i_ = 0; i_ < 4; i_++) {                          \
+    fa[i_][0] = rdA(kA, (HA_), i_, 0);                                        \
+    fa[i_][1] = rdA(kA, (HA_), i_, 1);                                        \
+  }
+#define N_RD_B(F_, BASE_)                                                     \
+  _Pragma("unroll") for (int j_ = 0; j_ < 2; j_++) {                          \
+    F_[j_][0] = rdB(BASE_, j_, 0);                                            \
+    F_[j_][1] = rdB(BASE_, j_, 1);                                            \
+  }
+#define N_MFMA(HA_, HB_, F_)                                                                                              \
+  __builtin_amdgcn_s_setprio(1);                                                                                          \
+  _Pragma("unroll") for (int s_ = 0; s_ < 2; s_++)                                                                        \
+  _Pragma("unroll") for (int i_ = 0; i_ < 4; i_++)                                                                        \
+  _Pragma("unroll") for (int j_ = 0; j_ < 2; j_++)                                                                        \
+    acc[HA_][HB_][i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F_[j_][s_], fa[i_][s_], acc[HA_][HB_][i_][j_], 0, 0, 0); \
+  __builtin_amdgcn_s_setprio(0);
+#define N_BAR()                                  \
+  __builtin_amdgcn_sched_barrier(0);             \
+  __builtin_amdgcn_s_barrier();                  \
+  __builtin_amdgcn_sched_barrier(0);
+#define N_LGKM0()                                          \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       \
+  __builtin_amdgcn_sched_barrier(0);
+#define N_VMCNT(n_) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(n_) : "memory")
+
+  // the two LDS-DMA streams (u >= nk: the K-tile u - nk of the workgroup's next tile; its last tile prefetches its own again)
+  const unsigned char* cA = (const unsigned char*)p.A + tm0 * p.lda * 2;
+  const unsigned char* nA = (const unsigned char*)p.A + nm0 * p.lda * 2;
+  const unsigned char* const Bp = (const unsigned char*)p.B;
+  const long long pieceA = 64 * p.lda * 2, pieceB = 128 * p.ldb * 2;
+  unsigned char* const aring = smem;
+  unsigned char* const bring = smem + N_ASLOTS * E_HALF;
+  // LDS-DMA with a UNIFORM 64-bit base and a 32-bit lane offset (the builtin form keeps a 64-bit address pair per stream in VGPRs and adds
+  // into it with the vector ALU; the compiler does not count these either)
+  auto dma2 = [&](const unsigned char* sbase, long long piece, unsigned voff, unsigned char* dst) {
+    const unsigned d0 = (unsigned)(unsigned long long)LDS_PTR(unsigned char, dst);
+    const unsigned char* s1 = sbase + piece;
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" :: "s"(sbase), "v"(voff), "s"(d0) : "memory", "m0");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" :: "s"(s1), "v"(voff), "s"(d0 + 8192u) : "memory", "m0");
+  };
+  auto issueA = [&](int u, int slot) {
+    const bool nx = u >= nk;
+    const long long uu = nx ? u - nk : u;
+    dma2((nx ? nA : cA) + uu * (E_BK * 2), pieceA, offA, aring + slot * E_HALF + wave * 1024);
+  };
+  auto issueB = [&](int u, int g, int h, int slot) {
+    const long long uu = u >= nk ? u - nk : u;
+    dma2(Bp + uu * (E_BK * 2) + (long long)(256 * g + 32 * h) * p.ldb * 2, pieceB, offB, bring + slot * E_HALF + wave * 1024);
+  };
+  auto mod6 = [](int x) -> int { return x >= 6 ? x - 6 : x; };
+  auto mod3 = [](int x) -> int { return x >= 3 ? x - 3 : x; };
+
+  // ---- prologue: K-tile 0 and A, B00, B10 of K-tile 1 (stream order as in the steady state)
+  issueA(0, 0); issueB(0, 0, 0, 0); issueB(0, 1, 0, 1); issueB(0, 0, 1, 2); issueB(0, 1, 1, 3);
+  issueA(1, 1); issueB(1, 0, 0, 4); issueB(1, 1, 0, 5);
+  N_VMCNT(6);
+  N_BAR();
+  if (wr == 1) { N_BAR(); }  // the stagger: waves 4-7 run one barrier behind
+
+  int ga = 0, gb = 0;        // ring positions of the current K-tile
+  bool first = true;
+
+  // epilogue addressing (see gemm_bf16_e256): after the column swap lane (li, lq) holds 8 columns of a 32-column block of row li; the values
+  // go through one lane transpose in LDS so that four adjacent lanes store 64 contiguous bytes of a row
+  const int cq = ((lq & 1) << 1) | (lq >> 1);
+  const int er = lane >> 2, ep = lane & 3;
+  const unsigned cvo = (unsigned)((er * p.ldc + 256 * wr + 64 * wc + 8 * ep) * 2);
+  const unsigned gvo = (unsigned)((er * p.ldr + 256 * wr + 64 * wc + 8 * ep) * 2);
+  const unsigned bvo = (unsigned)((64 * wc + 4 * lq) * 4);        // bias of the lane's accumulator columns: + (32 hb + 16 j) * 4
+  unsigned char* const xstg = smem + N_XSTG + wave * 2048;
+  const unsigned xw16 = (unsigned)(li * 64 + ((cq ^ ((li >> 1) & 3)) << 4));
+  const unsigned xr16 = (unsigned)(er * 64 + ((ep ^ ((er >> 1) & 3)) << 4));
+  const int xsw = (li ^ ((li >> 1) & 1)) & 7, xsr = (er ^ ((er >> 1) & 1)) & 7;
+  const unsigned xw32 = (unsigned)(li * 128), xr32 = (unsigned)(er * 128);
+  (void)xw16; (void)xr16; (void)xsw; (void)xsr; (void)xw32; (void)xr32; (void)gvo;
+  const ei4v brs = ersrc(BIAS ? (const void*)(p.bias + 256 * wr) : (const void*)p.B, 256 * 4);
+  eu4v side0[8], side1[8];   // residual rows 0-63 / 64-127 (EP_RESID)
+  eu4v biasr[4];             // the lane's 16 bias values as the accumulators hold them: [hb * 2 + j]
+
+  for (;;) {
+#pragma unroll
+    for (int ha = 0; ha < 2; ha++)
+#pragma unroll
+      for (int hb = 0; hb < 2; hb++)
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+          for (int j = 0; j < 2; j++) acc[ha][hb][i][j] = (f4v){0.f, 0.f, 0.f, 0.f};
+    const int spitch = (int)(p.ldr * 2);
+    const ei4v srs = ersrc(EPI == EP_RESID ? (const void*)((const bf16raw*)p.resid + tm0 * p.ldr) : (const void*)p.B, (unsigned)(128 * (EPI == EP_RESID ? spitch : 2)));
+
+    auto ktile = [&](auto last_c, auto t0_c, const int t) __attribute__((always_inline)) {
+      constexpr bool last = decltype(last_c)::value, t0 = decltype(t0_c)::value;
+      unsigned char* const kA = aring + ga * E_HALF;
+      unsigned char* const kB0 = bring + (gb + wr) * E_HALF;             // B(wr, 0): gb + wr <= 5
+      unsigned char* const kB1 = bring + mod6(gb + 2 + wr) * E_HALF;     // B(wr, 1)
+      // P1: A part 0 x B half 0
+      N_RD_B(fb0, kB0);
+      __builtin_amdgcn_sched_barrier(0);
+      N_RD_A(0);
+      issueA(t + 2, mod3(ga + 2));
+      asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");   // the B half 0 reads (issued first) are done: their slots are restaged in P2
+      // W2: B01 / B11 of this K-tile have landed (this wave's pieces).  Newer: B00 / B10 of t + 1, A(t+2); in a tile's first K-tile also the
+      // previous tile's side loads and stores
+      if (t0 && !first) N_VMCNT(6 + L0 + L1 + 2 * SH);
+      else N_VMCNT(6);
+      N_BAR();
+      N_LGKM0();
+      N_MFMA(0, 0, fb0);
+      N_BAR();
+      // P2: A part 0 x B half 1
+      N_RD_B(fb1, kB1);
+      issueB(t + 1, 0, 1, gb);
+      issueB(t + 1, 1, 1, gb + 1);
+      N_BAR();
+      N_LGKM0();
+      N_MFMA(0, 1, fb1);
+      N_BAR();
+      // P3: A part 1 x B half 1
+      N_RD_A(1);
+      N_BAR();
+      N_LGKM0();
+      N_MFMA(1, 1, fb1);
+      N_BAR();
+      // P4: A part 1 x B half 0
+      if (last && BIAS) {   // the epilogue's bias values and residual rows 0-63
+        E_BLOAD16(biasr[0], bvo, brs, 0, 0);      // [hb * 2 + j]: columns + 32 hb + 16 j
+        E_BLOAD16(biasr[1], bvo, brs, 0, 64);
+        E_BLOAD16(biasr[2], bvo, brs, 0, 128);
+        E_BLOAD16(biasr[3], bvo, brs, 0, 192);
+      }
+      if (last && EPI == EP_RESID) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const int so = 16 * i * spitch;
+          E_BLOAD16(side0[2 * i], gvo, srs, so, 0);
+          E_BLOAD16(side0[2 * i + 1], gvo, srs, so, 64);
+        }
+      }
+      issueB(t + 2, 0, 0, mod6(gb + 2));
+      issueB(t + 2, 1, 0, mod6(gb + 3));
+      // W1: A, B00, B10 of K-tile t + 1 have landed.  Newer: A(t+2), B01 / B11(t+1), B00 / B10(t+2) = 10; in a tile's first K-tile also the
+      // previous epilogue's second-half side loads and its stores, in its last the side loads just issued
+      if (t0 && !first) N_VMCNT(10 + L1 + 2 * SH);
+      else if (last) N_VMCNT(10 + L0);
+      else N_VMCNT(10);
+      N_BAR();
+      N_MFMA(1, 0, fb0);
+      N_BAR();
+      ga = mod3(ga + 1);
+      gb = mod6(gb + 4);
+    };
+    ktile(std::false_type{}, std::true_type{}, 0);
+    for (int t = 1; t < nk - 1; t++) ktile(std::false_type{}, std::false_type{}, t);
+    ktile(std::true_type{}, std::false_type{}, nk - 1);
+
+    // ---- epilogue, straight from the accumulators
+    first = false;
+    if (wr == 0) { N_BAR(); }   // undo the stagger: both groups run their epilogues side by side
+    {
+      const ei4v crs = ersrc((bf16raw*)p.C + tm0 * p.ldc, (unsigned)(128 * p.ldc * 2));
+      const int cpitch = (int)(p.ldc * 2);
+#pragma unroll
+      for (int ha = 0; ha < 2; ha++) {
+        if (ha == 0) {
+          // bias and rows 0-63: issued in phase 4 of the last K-tile; newer: B00 / B10 (4 instructions)
+          if (BIAS) E_WAIT4(4, biasr);
+          if (L1) E_WAIT8(4, side0);
+        }
+        if (L1 && ha == 1) E_WAIT8(SH / 2, side1);   // newer: the four stores of rows 32-63
+        f4v bx[2][2];
+#pragma unroll
+        for (int hb = 0; hb < 2; hb++)
+#pragma unroll
+          for (int j = 0; j < 2; j++) {
+            const eu4v b4 = biasr[hb * 2 + j];
+            bx[hb][j] = BIAS ? (f4v){__uint_as_float(b4[0]), __uint_as_float(b4[1]), __uint_as_float(b4[2]), __uint_as_float(b4[3])} : (f4v){0.f, 0.f, 0.f, 0.f};
+          }
+        constexpr int NI = EPI == EP_RESID ? 1 : 2;
+#pragma unroll
+        for (int ib = 0; ib < 4; ib += NI) {
+          if (L1 && ha == 0 && ib == 2) {
+            // rows 64-127 of the residual go out HALFWAY through rows 0-63: by then half of that half's accumulators and side registers are free
+            // (requested at the epilogue's start they sat beside everything else: 30-40 spilled registers and a vmcnt(0) at every reload)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+              const int so = (64 + 16 * i) * spitch;
+              E_BLOAD16(side1[2 * i], gvo, srs, so, 0);
+              E_BLOAD16(side1[2 * i + 1], gvo, srs, so, 64);
+            }
+          }
+          eu4v o[NI][2];
+#pragma unroll
+          for (int ii = 0; ii < NI; ii++)
+#pragma unroll
+            for (int hb = 0; hb < 2; hb++) {
+              const int i = ib + ii;
+              const f4v x = acc[ha][hb][i][0] + bx[hb][0];
+              const f4v y = acc[ha][hb][i][1] + bx[hb][1];
+              if (EPI == EP_RESID) {
+                float v[8];
+                *(f4v*)(xstg + xw32 + ((lq ^ xsw) << 4)) = x;
+                *(f4v*)(xstg + xw32 + (((4 + lq) ^ xsw) << 4)) = y;
+                const f4v r0 = *(const f4v*)(xstg + xr32 + (((2 * ep) ^ xsr) << 4));
+                const f4v r1 = *(const f4v*)(xstg + xr32 + (((2 * ep + 1) ^ xsr) << 4));
+#pragma unroll
+                for (int e = 0; e < 4; e++) { v[e] = r0[e]; v[4 + e] = r1[e]; }
+                const eu4v r4 = ha ? side1[2 * i + hb] : side0[2 * i + hb];
+#pragma unroll
+                for (int e = 0; e < 4; e++) { v[2 * e] += __uint_as_float(r4[e] << 16); v[2 * e + 1] += __uint_as_float(r4[e] & 0xffff0000u); }
+                o[ii][hb][0] = pack2bf(v[0], v[1]); o[ii][hb][1] = pack2bf(v[2], v[3]); o[ii][hb][2] = pack2bf(v[4], v[5]); o[ii][hb][3] = pack2bf(v[6], v[7]);
+              } else {
+                const unsigned px0 = pack2bf(x[0], x[1]), px1 = pack2bf(x[2], x[3]);
+                const unsigned py0 = pack2bf(y[0], y[1]), py1 = pack2bf(y[2], y[3]);
+                auto s0 = __builtin_amdgcn_permlane16_swap(px0, py0, false, false);
+                auto s1 = __builtin_amdgcn_permlane16_swap(px1, py1, false, false);
+                *(eu4v*)(xstg + hb * 1024 + xw16) = (eu4v){s0[0], s1[0], s0[1], s1[1]};
+                o[ii][hb] = *(const eu4v*)(xstg + hb * 1024 + xr16);
+              }
+            }
+#pragma unroll
+          for (int ii = 0; ii < NI; ii++) {
+            const int i = ib + ii;
+            const int so = (64 * ha + 16 * i) * cpitch;
+#pragma unroll
+            for (int hb = 0; hb < 2; hb++) {
+              eu4v& ou = o[ii][hb];
+              if (hb) E_BSTORE16(ou, cvo, crs, so, 64); else E_BSTORE16(ou, cvo, crs, so, 0);
+            }
+          }
+        }
+      }
+    }
+    if (!has_next) break;
+    T += G;
+    tm0 = nm0; cA = nA;
+    has_next = T + G < nt;
+    nm0 = tile_of(has_next ? T + G : T);
+    nA = (const unsigned char*)p.A + nm0 * p.lda * 2;
+    if (wr == 1) { N_BAR(); }  // the stagger again
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last tile's surplus prefetches land before the LDS is released
+#undef N_RD_A
+#undef N_RD_B
+#undef N_MFMA
+#undef N_BAR
+#undef N_LGKM0
+#undef N_VMCNT
+}
+int g_gemm_nw = 0;   // pero_set_option("gemm_nw", 1): N = 512 stored products with the plain / residual epilogue on the row-complete tile
+bool pero_launch_gemm_n512(const GemmP& p0, long long batch, bool ta, bool tb, bool out_f32, hipStream_t st) {
+  if (!g_gemm_nw || batch != 1 || ta || tb || out_f32 || p0.N != 512 || p0.M % N_BM || p0.K % E_BK || p0.K < 3 * E_BK) return false;
+  if (p0.alpha != 1.0f || p0.gate || (p0.flags & ~(PERO_GEMM_TILE256))) return false;   // bias and residual only
+  if (p0.lda >= (1LL << 22) || p0.ldb >= (1LL << 22) || p0.ldc >= (1LL << 22) || (p0.resid && p0.ldr >= (1LL << 22))) return false;
+  int num_cus = (pero_num_cus() / 8) * 8;
+  if (num_cus < 8) num_cus = 8;
+  const long long nt = p0.M / N_BM;
+  const unsigned G = (unsigned)(nt < num_cus ? ((nt + 7) / 8) * 8 : num_cus);
+  GemmP p = p0;
+#define LAUNCH_N(EP_, BI_)                                                                          \
+  do {                                                                                              \
+    PERO_LDS_ATTR((gemm_bf16_n512<EP_, BI_>), N_LDS_BYTES);                                          \
+    hipLaunchKernelGGL((gemm_bf16_n512<EP_, BI_>), dim3(G), dim3(512), N_LDS_BYTES, st, p);          \
+  } while (0)
+  if (p0.resid) { if (p0.bias) LAUNCH_N(EP_RESID, true); else LAUNCH_N(EP_RESID, false); }
+  else { if (p0.bias) LAUNCH_N(EP_PLAIN, true); else LAUNCH_N(EP_PLAIN, false); }
+#undef LAUNCH_N
+  return true;
+}
+
 // C[tile] += alpha * sum over the slices (in slice order) of the partial tiles the split-K work items left in the workspace.
 // One thread per float4 position of a tile: consecutive threads read consecutive 16 bytes of every partial tile.
 __global__ __launch_bounds__(256) void pero_splitk_reduce_k(const f4v* ws, float* C, long long ldc, int ntn, int nsl, float alpha, bool vec4) {
