@@ -183,3 +183,38 @@ def test_strided_views_of_every_operand(e256):
     assert torch.all(ca[:, :256] == 7.0) and torch.all(ca[:, 256 + N:] == 7.0)
     ref = x.float() @ w.float().t() + bias + res.float()
     assert float((ca[:, 256:256 + N].float() - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("M,K", [(1024, 192), (2176, 512), (65536, 1536), (131072, 2048)])
+def test_row_complete_tile_gives_the_bits_of_the_256x256_tile(e256, M, K):
+    """gemm_bf16_n512 (opt-in "gemm_nw": one workgroup = 128 rows x all 512 columns, the tile the fused LayerNorm epilogues need): the same
+    K-tile order and the same MFMA order per output as gemm_bf16_e256, so plain / bias / residual products must agree bit for bit (M % 256
+    != 0, which the 256-row tile does not take: against the f32 product); repeated launches give identical bytes (a missed counted wait shows
+    as run-to-run differences); operands and output as column-slice views (leading dimensions larger than the rows)."""
+    ops = e256
+    from pero_pretraining_amd import _lib
+    L = _lib.lib()
+    torch.manual_seed(9)
+    N = 512
+    xa = (torch.randn(M, K + 64, device="cuda") * 0.5).bfloat16()
+    wa = (torch.randn(N, K + 128, device="cuda") * 0.5).bfloat16()
+    ra = torch.randn(M, N + 256, device="cuda").bfloat16()
+    x, w, res = xa[:, 64:], wa[:, :K], ra[:, 128:128 + N]
+    bias = torch.randn(N, device="cuda")
+    try:
+        for kw in ({}, {"bias": bias}, {"residual": res}, {"bias": bias, "residual": res}):
+            L.pero_set_option(b"gemm_nw", 0)
+            want = ops.gemm(x, w, **kw) if M % 256 == 0 else None
+            L.pero_set_option(b"gemm_nw", 1)
+            ca = torch.full((M, N + 512), 7.0, device="cuda").bfloat16()
+            got = ops.gemm(x, w, out=ca[:, 256:256 + N], **kw)
+            if want is not None:
+                assert torch.equal(got, want), kw
+            else:
+                ref = x.float() @ w.float().t() + (bias if "bias" in kw else 0) + (res.float() if "residual" in kw else 0)
+                assert float((got.float() - ref).abs().max()) <= 2e-2 * float(ref.abs().max()), kw
+            assert torch.all(ca[:, :256] == 7.0) and torch.all(ca[:, 256 + N:] == 7.0)
+            for _ in range(5):
+                assert torch.equal(ops.gemm(x, w, **kw), got), kw
+    finally:
+        L.pero_set_option(b"gemm_nw", 0)
