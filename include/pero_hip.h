@@ -110,6 +110,15 @@ int pero_gemm(const void* A, const void* B, void* C, const float* bias, const vo
  * Depends on the arguments and the pero_set_option knobs only (no device query). */
 int64_t pero_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K, int64_t batch, int flags, int k_split, int in_dtype, int out_dtype);
 
+/* Linear + residual + LayerNorm in ONE launch (bf16; N = 512, M % 128 == 0, K % 64 == 0, K >= 192): Y = A W^T + bias + R stored (the backward
+ * reads it), T = LayerNorm(Y) * gamma + beta computed from the rounded rows of Y exactly as pero_layernorm_fwd does, mean / rstd f32 per row.
+ * Replaces the pair (Linear with the residual add, torch.nn.LayerNorm) of TransformerEncoderLayer's post-norm blocks
+ * (x = norm1(x + out_proj(attn)), x = norm2(x + linear2(...)): models/transformers.py:36-43) - the LayerNorm's read of Y goes away.
+ * bias may be null.  PERO_E_INVALID for other shapes: the caller falls back to pero_gemm + pero_layernorm_fwd. */
+int pero_gemm_resid_layernorm(const void* A, const void* W, const float* bias, const void* R, const float* gamma, const float* beta,
+                              void* Y, void* T, float* mean, float* rstd, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw,
+                              int64_t ldy, int64_t ldr, int64_t ldt, float eps, void* stream);
+
 /* ---- LayerNorm (+ positional encoding) --------------------------------------------------------------
  * y = (x - mean) * rstd * gamma + beta (+ pe[offsets[row / S] + row % S]) ; rows x d.
  * Replaces torch.nn.LayerNorm (models/transformers.py:28,83-84 and the norm1/norm2 of

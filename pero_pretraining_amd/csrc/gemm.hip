@@ -410,6 +410,25 @@ static bool splitk_takes_e256(int64_t M, int64_t N, int64_t K, int flags) {
   return can256 && K % 64 == 0 && K >= 128 &&
          (g_gemm_policy == 20 || (g_gemm_policy == 0 && ((flags & PERO_GEMM_TILE256) || (g_gemm_e256_min > 0 && K >= 32768 && t256 >= g_gemm_e_splitk_min))));
 }
+// Linear + residual + LayerNorm in one launch (the row-complete 128 x 512 tile of gemm_e.hip): Y = A W^T + bias + R (bf16, stored: the backward
+// needs it), T = (Y - mean) * rstd * gamma + beta over the ROUNDED rows of Y (layernorm_fwd4_k's arithmetic), mean / rstd (f32 per row).
+extern "C" int pero_gemm_resid_layernorm(const void* A, const void* W, const float* bias, const void* R, const float* gamma, const float* beta,
+                                         void* Y, void* T, float* mean, float* rstd, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw,
+                                         int64_t ldy, int64_t ldr, int64_t ldt, float eps, void* stream) {
+  PERO_REQUIRE(A && W && R && gamma && beta && Y && T && mean && rstd, "pero_gemm_resid_layernorm: null pointer");
+  PERO_REQUIRE(N == 512 && M > 0 && M % 128 == 0 && K % 64 == 0 && K >= 192 && lda % 8 == 0 && ldw % 8 == 0 && ldy % 8 == 0 && ldr % 8 == 0 &&
+               ldt % 8 == 0 && aligned16(A) && aligned16(W) && aligned16(R) && aligned16(Y) && aligned16(T) && aligned16(gamma) && aligned16(beta) &&
+               (!bias || aligned16(bias)),
+               "pero_gemm_resid_layernorm: bf16, N = 512, M %% 128 == 0, K %% 64 == 0, K >= 192, 16-byte aligned rows");
+  GemmP p;
+  p.A = A; p.B = W; p.C = Y; p.bias = bias; p.resid = R; p.gate = nullptr;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldw; p.ldc = ldy; p.ldr = ldr; p.ldg = 0;
+  p.sAo = p.sAi = p.sBo = p.sBi = p.sCo = p.sCi = 0;
+  p.binner = 1; p.alpha = 1.0f; p.flags = 0; p.kchunk = K;
+  PERO_REQUIRE(pero_launch_gemm_n512_ln(p, T, ldt, mean, rstd, gamma, beta, eps, (hipStream_t)stream), "pero_gemm_resid_layernorm: shape not taken");
+  PERO_CHECK_LAUNCH("pero_gemm_resid_layernorm");
+  return PERO_OK;
+}
 extern "C" int64_t pero_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K, int64_t batch, int flags, int k_split, int in_dtype,
                                              int out_dtype) {
   if (!(flags & PERO_GEMM_ATOMIC) || batch != 1 || in_dtype != PERO_BF16 || out_dtype != PERO_F32 || (flags & PERO_GEMM_FORCE_GENERIC) || M <= 0 ||

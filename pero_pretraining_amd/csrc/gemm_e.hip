@@ -59,6 +59,9 @@
 #define EP_GATE_BITS 4   // `gate` bit mask applied; with PERO_GEMM_COLSUM the column sums of the stored result are added to `bias`
 #define EP_ROWDOT 6      // `bias`[m][n / 128] += row dots of the stored result with `gate` (bf16 rows of C's shape)
 #define EP_SPLITK 7      // f32 C += partial product of ONE k-slice (atomics): one work item (tile, k-slice) per workgroup, not persistent
+#define EP_RESID_LN 8    // (gemm_bf16_n512 only) bias, + residual -> y stored; LayerNorm of the stored rows -> t, mean, rstd (LnP)
+// second argument of gemm_bf16_n512: what the LayerNorm epilogue writes and reads beside GemmP
+struct LnP { void* t; long long ldt; float* mean; float* rstd; const float* gamma; const float* beta; float eps; };
 
 typedef int ei4v __attribute__((ext_vector_type(4)));
 typedef short es2v __attribute__((ext_vector_type(2)));
@@ -126,10 +129,14 @@ __device__ __forceinline__ ei4v ersrc(const void* base, unsigned bytes) {
 // 16-byte store: its data registers are rewritten by the next unit right behind it.  hipcc (ROCm 7.2) pads that hazard only for
 // a constant soffset; with the row offset in an SGPR the store sent stale dwords for some lanes (measured: lanes 12-15 of the
 // second data dword) - the wait states are in the string
+// ... and IN FRONT of it: the compiler does not look into the string, so nothing keeps a v_readlane_b32 that restores a spilled SGPR (the row
+// offset, the descriptor) apart from the store that reads it - a vector-ALU write of an SGPR needs five wait states before a vector-memory
+// instruction uses it, and a store issued too early takes the SGPR's OLD value: rows of the LayerNorm epilogue (87 spilled SGPRs) landed in
+// other row groups, run-to-run different (E_BLOAD16 has had its s_nop 4 for the same reason)
 #define E_BSTORE16(src_, voff_, rs_, soff_, imm_) \
-  asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen offset:%4\n\ts_nop 2" :: "v"(src_), "v"(voff_), "s"(rs_), "s"(soff_), "i"(imm_) : "memory")
+  asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen offset:%4\n\ts_nop 2" :: "v"(src_), "v"(voff_), "s"(rs_), "s"(soff_), "i"(imm_) : "memory")
 #define E_BSTORE16_NT(src_, voff_, rs_, soff_, imm_) \
-  asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen offset:%4 nt\n\ts_nop 2" :: "v"(src_), "v"(voff_), "s"(rs_), "s"(soff_), "i"(imm_) : "memory")
+  asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen offset:%4 nt\n\ts_nop 2" :: "v"(src_), "v"(voff_), "s"(rs_), "s"(soff_), "i"(imm_) : "memory")
 #define E_WAIT8(n_, r_) \
   asm volatile("s_waitcnt vmcnt(%8)" : "+v"(r_[0]), "+v"(r_[1]), "+v"(r_[2]), "+v"(r_[3]), "+v"(r_[4]), "+v"(r_[5]), "+v"(r_[6]), "+v"(r_[7]) : "i"(n_) : "memory")
 #define E_WAIT4(n_, r_) \
@@ -831,6 +838,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p, int ks) {
 //    instructions) and W1 in phase 4 (A, B00, B10 of t + 1: newer are A(t+2), B01 / B11(t+1), B00 / B10(t+2) = 10); in a tile's first K-tile the
 //    previous epilogue's side loads and stores, in its last the side loads of its own epilogue are counted out (constants at the waits).
 // Epilogue: gemm_bf16_e256's plain / residual epilogue with `128 wr` gone from the row offsets and `256 wr` added to the columns.
+#ifndef N_DBG
+#define N_DBG 0   // bring-up switches of the LayerNorm epilogue: 1 no gamma / beta loads (gamma = 1, beta = 0), 2 no mean / rstd stores, 4 pass 2 recomputes nothing (stores y again)
+#endif
 #define N_BM 128
 #define N_ASLOTS 3
 #define N_BSLOTS 6
@@ -839,13 +849,18 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p, int ks) {
 #define N_LDS_BYTES (N_XSTG + 8 * 2048)              // 163 840 = the CU's 160 KiB
 
 template <int EPI, bool BIAS>
-__global__ __launch_bounds__(512, 2) void gemm_bf16_n512(GemmP p) {
+__global__ __launch_bounds__(512, 2) void gemm_bf16_n512(GemmP p, LnP q) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  static_assert(EPI == EP_PLAIN || EPI == EP_RESID, "the row-complete tile has the plain and the residual epilogue");
+  static_assert(EPI == EP_PLAIN || EPI == EP_RESID || EPI == EP_RESID_LN, "the row-complete tile has the plain, the residual and the residual + LayerNorm epilogue");
+  constexpr bool LN = EPI == EP_RESID_LN;
+  constexpr bool RES = EPI == EP_RESID || LN;
   constexpr int LB = BIAS ? 4 : 0;                        // bias side loads (16 B per lane each)
-  constexpr int L0 = LB + (EPI == EP_RESID ? 8 : 0);      // side loads issued in phase 4 of the last K-tile: bias + residual rows 0-63
-  constexpr int L1 = EPI == EP_RESID ? 8 : 0;             // residual rows 64-127, issued at the epilogue's start
+  constexpr int L0 = LB + (RES ? 8 : 0);                  // side loads issued in phase 4 of the last K-tile: bias + residual rows 0-63
+  constexpr int L1 = RES ? 8 : 0;                         // residual rows 64-127, issued halfway through rows 0-63
   constexpr int SH = 8;                                   // stores per half of the epilogue
+  constexpr int LNX = LN ? 8 + 2 + 16 : 0;                // LayerNorm: gamma / beta loads, mean / rstd stores, the 16 stores of t
+  constexpr int EPO = L1 + 2 * SH + LNX;                  // vector-memory operations of an epilogue behind its phase-4 side loads
+  constexpr int cap63 = 63;                               // s_waitcnt vmcnt takes six bits: a larger count only asks for more than needed
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;                // wr: N-tile (columns 256 wr ...), wc: its 64-column strip
@@ -913,8 +928,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_n512(GemmP p) {
   auto dma2 = [&](const unsigned char* sbase, long long piece, unsigned voff, unsigned char* dst) {
     const unsigned d0 = (unsigned)(unsigned long long)LDS_PTR(unsigned char, dst);
     const unsigned char* s1 = sbase + piece;
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" :: "s"(sbase), "v"(voff), "s"(d0) : "memory", "m0");
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" :: "s"(s1), "v"(voff), "s"(d0 + 8192u) : "memory", "m0");
+    // (s_nop 3: with the s_mov five wait states between a v_readlane_b32 that restores a spilled base and the load that reads it - the
+    //  compiler pads that hazard for its own instructions only, tools/check_async_loads.py finds the unpadded ones)
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %1, %0" :: "s"(sbase), "v"(voff), "s"(d0) : "memory", "m0");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %1, %0" :: "s"(s1), "v"(voff), "s"(d0 + 8192u) : "memory", "m0");
   };
   auto issueA = [&](int u, int slot) {
     const bool nx = u >= nk;
@@ -938,19 +955,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_n512(GemmP p) {
   int ga = 0, gb = 0;        // ring positions of the current K-tile
   bool first = true;
 
-  // epilogue addressing (see gemm_bf16_e256): after the column swap lane (li, lq) holds 8 columns of a 32-column block of row li; the values
-  // go through one lane transpose in LDS so that four adjacent lanes store 64 contiguous bytes of a row
-  const int cq = ((lq & 1) << 1) | (lq >> 1);
-  const int er = lane >> 2, ep = lane & 3;
-  const unsigned cvo = (unsigned)((er * p.ldc + 256 * wr + 64 * wc + 8 * ep) * 2);
-  const unsigned gvo = (unsigned)((er * p.ldr + 256 * wr + 64 * wc + 8 * ep) * 2);
-  const unsigned bvo = (unsigned)((64 * wc + 4 * lq) * 4);        // bias of the lane's accumulator columns: + (32 hb + 16 j) * 4
   unsigned char* const xstg = smem + N_XSTG + wave * 2048;
-  const unsigned xw16 = (unsigned)(li * 64 + ((cq ^ ((li >> 1) & 3)) << 4));
-  const unsigned xr16 = (unsigned)(er * 64 + ((ep ^ ((er >> 1) & 3)) << 4));
-  const int xsw = (li ^ ((li >> 1) & 1)) & 7, xsr = (er ^ ((er >> 1) & 1)) & 7;
-  const unsigned xw32 = (unsigned)(li * 128), xr32 = (unsigned)(er * 128);
-  (void)xw16; (void)xr16; (void)xsw; (void)xsr; (void)xw32; (void)xr32; (void)gvo;
   const ei4v brs = ersrc(BIAS ? (const void*)(p.bias + 256 * wr) : (const void*)p.B, 256 * 4);
   eu4v side0[8], side1[8];   // residual rows 0-63 / 64-127 (EP_RESID)
   eu4v biasr[4];             // the lane's 16 bias values as the accumulators hold them: [hb * 2 + j]
@@ -965,7 +970,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_n512(GemmP p) {
 #pragma unroll
           for (int j = 0; j < 2; j++) acc[ha][hb][i][j] = (f4v){0.f, 0.f, 0.f, 0.f};
     const int spitch = (int)(p.ldr * 2);
-    const ei4v srs = ersrc(EPI == EP_RESID ? (const void*)((const bf16raw*)p.resid + tm0 * p.ldr) : (const void*)p.B, (unsigned)(128 * (EPI == EP_RESID ? spitch : 2)));
+    const ei4v srs = ersrc(RES ? (const void*)((const bf16raw*)p.resid + tm0 * p.ldr) : (const void*)p.B, (unsigned)(128 * (RES ? spitch : 2)));
 
     auto ktile = [&](auto last_c, auto t0_c, const int t) __attribute__((always_inline)) {
       constexpr bool last = decltype(last_c)::value, t0 = decltype(t0_c)::value;
@@ -980,7 +985,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_n512(GemmP p) {
       asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");   // the B half 0 reads (issued first) are done: their slots are restaged in P2
       // W2: B01 / B11 of this K-tile have landed (this wave's pieces).  Newer: B00 / B10 of t + 1, A(t+2); in a tile's first K-tile also the
       // previous tile's side loads and stores
-      if (t0 && !first) N_VMCNT(6 + L0 + L1 + 2 * SH);
+      if (t0 && !first) N_VMCNT((6 + L0 + EPO) < cap63 ? (6 + L0 + EPO) : cap63);
       else N_VMCNT(6);
       N_BAR();
       N_LGKM0();
@@ -1001,13 +1006,18 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_n512(GemmP p) {
       N_MFMA(1, 1, fb1);
       N_BAR();
       // P4: A part 1 x B half 0
+      int lane_p = lane;   // (opaque copy: the side-load offsets are computed here, not carried through the main loop)
+      if (last) asm volatile("" : "+v"(lane_p));
+      const unsigned bvo = (unsigned)((64 * wc + 4 * (lane_p >> 4)) * 4);        // bias of the lane's accumulator columns: + (32 hb + 16 j) * 4
+      const unsigned gvo = (unsigned)(((lane_p >> 2) * p.ldr + 256 * wr + 64 * wc + 8 * (lane_p & 3)) * 2);
+      (void)bvo; (void)gvo;
       if (last && BIAS) {   // the epilogue's bias values and residual rows 0-63
         E_BLOAD16(biasr[0], bvo, brs, 0, 0);      // [hb * 2 + j]: columns + 32 hb + 16 j
         E_BLOAD16(biasr[1], bvo, brs, 0, 64);
         E_BLOAD16(biasr[2], bvo, brs, 0, 128);
         E_BLOAD16(biasr[3], bvo, brs, 0, 192);
       }
-      if (last && EPI == EP_RESID) {
+      if (last && RES) {
 #pragma unroll
         for (int i = 0; i < 4; i++) {
           const int so = 16 * i * spitch;
@@ -1019,7 +1029,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_n512(GemmP p) {
       issueB(t + 2, 1, 0, mod6(gb + 3));
       // W1: A, B00, B10 of K-tile t + 1 have landed.  Newer: A(t+2), B01 / B11(t+1), B00 / B10(t+2) = 10; in a tile's first K-tile also the
       // previous epilogue's second-half side loads and its stores, in its last the side loads just issued
-      if (t0 && !first) N_VMCNT(10 + L1 + 2 * SH);
+      if (t0 && !first) N_VMCNT((10 + EPO) < cap63 ? (10 + EPO) : cap63);
       else if (last) N_VMCNT(10 + L0);
       else N_VMCNT(10);
       N_BAR();
@@ -1036,8 +1046,28 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_n512(GemmP p) {
     first = false;
     if (wr == 0) { N_BAR(); }   // undo the stagger: both groups run their epilogues side by side
     {
+      // epilogue addressing (see gemm_bf16_e256): after the column swap lane (li, lq) holds 8 columns of a 32-column block of row li; the values
+      // go through one lane transpose in LDS so that four adjacent lanes store 64 contiguous bytes of a row.  Derived HERE from an opaque copy of
+      // the lane index: as loop invariants the compiler parked two dozen of them in scratch across the main loop and reloaded them in the
+      // epilogue - every reload a vector-memory operation in the counted queue with a vmcnt(0) behind it
+      int lane_e = lane;
+      asm volatile("" : "+v"(lane_e));
+      const int li_e = lane_e & 15, lq_e = lane_e >> 4;
+      const int cq = ((lq_e & 1) << 1) | (lq_e >> 1);
+      const int er = lane_e >> 2, ep = lane_e & 3;
+      const unsigned cvo = (unsigned)((er * p.ldc + 256 * wr + 64 * wc + 8 * ep) * 2);
+      const unsigned gvo = (unsigned)((er * p.ldr + 256 * wr + 64 * wc + 8 * ep) * 2);
+      const unsigned xw16 = (unsigned)(li_e * 64 + ((cq ^ ((li_e >> 1) & 3)) << 4));
+      const unsigned xr16 = (unsigned)(er * 64 + ((ep ^ ((er >> 1) & 3)) << 4));
+      const int xsw = (li_e ^ ((li_e >> 1) & 1)) & 7, xsr = (er ^ ((er >> 1) & 1)) & 7;
+      const unsigned xw32 = (unsigned)(li_e * 128), xr32 = (unsigned)(er * 128);
+      (void)xw16; (void)xr16; (void)xsw; (void)xsr; (void)xw32; (void)xr32; (void)gvo; (void)cq;
       const ei4v crs = ersrc((bf16raw*)p.C + tm0 * p.ldc, (unsigned)(128 * p.ldc * 2));
       const int cpitch = (int)(p.ldc * 2);
+      eu4v yk[2][4][2];   // LN: the packed rows of y, kept for the statistics and the normalisation (the accumulators die as they are consumed)
+      float rsum[2][4];   // LN: this lane's share of the row sums (rows 64 ha + 16 i + er, its 16 columns)
+      eu4v gb[8];         // LN: gamma / beta of the lane's 16 columns: [hb][half] then + 4
+      (void)yk; (void)rsum; (void)gb;
 #pragma unroll
       for (int ha = 0; ha < 2; ha++) {
         if (ha == 0) {
@@ -1054,7 +1084,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_n512(GemmP p) {
             const eu4v b4 = biasr[hb * 2 + j];
             bx[hb][j] = BIAS ? (f4v){__uint_as_float(b4[0]), __uint_as_float(b4[1]), __uint_as_float(b4[2]), __uint_as_float(b4[3])} : (f4v){0.f, 0.f, 0.f, 0.f};
           }
-        constexpr int NI = EPI == EP_RESID ? 1 : 2;
+        constexpr int NI = RES ? 1 : 2;
 #pragma unroll
         for (int ib = 0; ib < 4; ib += NI) {
           if (L1 && ha == 0 && ib == 2) {
@@ -1067,6 +1097,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_n512(GemmP p) {
               E_BLOAD16(side1[2 * i + 1], gvo, srs, so, 64);
             }
           }
+          if (LN && !(N_DBG & 1) && ha == 1 && ib == 2) {   // (three quarters of the accumulators and side registers are free by now; only the four stores of rows 96-127 follow)
+            // gamma / beta of the lane's columns 256 wr + 64 wc + 32 hb + 8 ep .. + 7 (two 16-byte halves each): needed in pass 2
+            const ei4v grs = ersrc(q.gamma + 256 * wr + 64 * wc, 64 * 4), ers = ersrc(q.beta + 256 * wr + 64 * wc, 64 * 4);
+            const unsigned gvoff = (unsigned)(8 * ep * 4);
+            E_BLOAD16(gb[0], gvoff, grs, 0, 0); E_BLOAD16(gb[1], gvoff, grs, 0, 16); E_BLOAD16(gb[2], gvoff, grs, 0, 128); E_BLOAD16(gb[3], gvoff, grs, 0, 144);
+            E_BLOAD16(gb[4], gvoff, ers, 0, 0); E_BLOAD16(gb[5], gvoff, ers, 0, 16); E_BLOAD16(gb[6], gvoff, ers, 0, 128); E_BLOAD16(gb[7], gvoff, ers, 0, 144);
+          }
           eu4v o[NI][2];
 #pragma unroll
           for (int ii = 0; ii < NI; ii++)
@@ -1075,10 +1112,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_n512(GemmP p) {
               const int i = ib + ii;
               const f4v x = acc[ha][hb][i][0] + bx[hb][0];
               const f4v y = acc[ha][hb][i][1] + bx[hb][1];
-              if (EPI == EP_RESID) {
+              if (RES) {
                 float v[8];
-                *(f4v*)(xstg + xw32 + ((lq ^ xsw) << 4)) = x;
-                *(f4v*)(xstg + xw32 + (((4 + lq) ^ xsw) << 4)) = y;
+                *(f4v*)(xstg + xw32 + ((lq_e ^ xsw) << 4)) = x;
+                *(f4v*)(xstg + xw32 + (((4 + lq_e) ^ xsw) << 4)) = y;
                 const f4v r0 = *(const f4v*)(xstg + xr32 + (((2 * ep) ^ xsr) << 4));
                 const f4v r1 = *(const f4v*)(xstg + xr32 + (((2 * ep + 1) ^ xsr) << 4));
 #pragma unroll
@@ -1087,6 +1124,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_n512(GemmP p) {
 #pragma unroll
                 for (int e = 0; e < 4; e++) { v[2 * e] += __uint_as_float(r4[e] << 16); v[2 * e + 1] += __uint_as_float(r4[e] & 0xffff0000u); }
                 o[ii][hb][0] = pack2bf(v[0], v[1]); o[ii][hb][1] = pack2bf(v[2], v[3]); o[ii][hb][2] = pack2bf(v[4], v[5]); o[ii][hb][3] = pack2bf(v[6], v[7]);
+                if (LN) {
+                  yk[ha][i][hb] = o[ii][hb];
+                  float sacc = hb ? rsum[ha][i] : 0.f;   // the LayerNorm kernel sums the ROUNDED values (layernorm_fwd4_k)
+#pragma unroll
+                  for (int e = 0; e < 4; e++) { sacc += __uint_as_float(o[ii][hb][e] << 16); sacc += __uint_as_float(o[ii][hb][e] & 0xffff0000u); }
+                  rsum[ha][i] = sacc;
+                }
               } else {
                 const unsigned px0 = pack2bf(x[0], x[1]), px1 = pack2bf(x[2], x[3]);
                 const unsigned py0 = pack2bf(y[0], y[1]), py1 = pack2bf(y[2], y[3]);
@@ -1107,6 +1151,82 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_n512(GemmP p) {
             }
           }
         }
+      }
+      if (LN) {
+        // ---- the LayerNorm of the stored rows (layernorm_fwd4_k's arithmetic: mean, then the centred squares, both over the rounded values).
+        // A row's 512 columns are spread over the eight waves: every wave leaves its 128 row partials in its own staging block (idle now),
+        // one workgroup barrier, and lane (er, ep) adds the partials of waves 2 ep, 2 ep + 1 for its eight rows; a quad sum gives the total.
+        float* const mine = (float*)xstg;                                    // [2][128] floats of this wave
+        const float* const all = (const float*)(smem + N_XSTG);              // wave w: + 512 w floats
+        auto quad = [&](float v) -> float {
+          v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xf, 0xf, false));
+          v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xf, 0xf, false));
+          return v;
+        };
+        auto exchange = [&](float (&part)[2][4], int which) {   // in: this lane's shares; out: the totals of its eight rows
+#pragma unroll
+          for (int ha = 0; ha < 2; ha++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+              const float w = quad(part[ha][i]);
+              if (ep == 0) mine[which * 128 + 64 * ha + 16 * i + er] = w;
+            }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          N_BAR();
+#pragma unroll
+          for (int ha = 0; ha < 2; ha++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+              const int r = which * 128 + 64 * ha + 16 * i + er;
+              part[ha][i] = quad(all[(2 * ep) * 512 + r] + all[(2 * ep + 1) * 512 + r]);
+            }
+        };
+        if (!(N_DBG & 8)) exchange(rsum, 0);
+        float mu[2][4], qs[2][4];
+#pragma unroll
+        for (int ha = 0; ha < 2; ha++)
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            mu[ha][i] = rsum[ha][i] / 512.f;
+            float a = 0.f;
+#pragma unroll
+            for (int hb = 0; hb < 2; hb++)
+#pragma unroll
+              for (int e = 0; e < 4; e++) {
+                const float t0 = __uint_as_float(yk[ha][i][hb][e] << 16) - mu[ha][i], t1 = __uint_as_float(yk[ha][i][hb][e] & 0xffff0000u) - mu[ha][i];
+                a += t0 * t0; a += t1 * t1;
+              }
+            qs[ha][i] = a;
+          }
+        if (!(N_DBG & 8)) exchange(qs, 1);
+        // mean / rstd of the tile's rows: wave w writes the 16 rows of its (ha, i) = (w >> 2, w & 3)
+        if (!(N_DBG & 1)) E_WAIT8(SH / 2, gb);   // gamma / beta: newer are the four stores of rows 96-127
+        const ei4v trs = ersrc((bf16raw*)q.t + tm0 * q.ldt, (unsigned)(128 * q.ldt * 2));
+        const int tpitch = (int)(q.ldt * 2);
+        const unsigned tvo = (unsigned)((er * q.ldt + 256 * wr + 64 * wc + 8 * ep) * 2);
+#pragma unroll
+        for (int ha = 0; ha < 2; ha++)
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const float rs = 1.0f / sqrtf(qs[ha][i] / 512.f + q.eps);
+            if (!(N_DBG & 2) && wave == ha * 4 + i && ep == 0) {
+              q.mean[tm0 + 64 * ha + 16 * i + er] = mu[ha][i];
+              q.rstd[tm0 + 64 * ha + 16 * i + er] = rs;
+            }
+#pragma unroll
+            for (int hb = 0; hb < 2; hb++) {
+              eu4v ot;
+#pragma unroll
+              for (int e = 0; e < 4; e++) {
+                const float g0 = (N_DBG & 1) ? 1.f : __uint_as_float(gb[2 * hb + (e >> 1)][2 * (e & 1)]), g1 = (N_DBG & 1) ? 1.f : __uint_as_float(gb[2 * hb + (e >> 1)][2 * (e & 1) + 1]);
+                const float b0 = (N_DBG & 1) ? 0.f : __uint_as_float(gb[4 + 2 * hb + (e >> 1)][2 * (e & 1)]), b1 = (N_DBG & 1) ? 0.f : __uint_as_float(gb[4 + 2 * hb + (e >> 1)][2 * (e & 1) + 1]);
+                const float v0 = __uint_as_float(yk[ha][i][hb][e] << 16), v1 = __uint_as_float(yk[ha][i][hb][e] & 0xffff0000u);
+                ot[e] = (N_DBG & 4) ? yk[ha][i][hb][e] : pack2bf((v0 - mu[ha][i]) * rs * g0 + b0, (v1 - mu[ha][i]) * rs * g1 + b1);
+              }
+              const int so = (64 * ha + 16 * i) * tpitch;
+              if (hb) E_BSTORE16(ot, tvo, trs, so, 64); else E_BSTORE16(ot, tvo, trs, so, 0);
+            }
+          }
       }
     }
     if (!has_next) break;
@@ -1135,13 +1255,29 @@ bool pero_launch_gemm_n512(const GemmP& p0, long long batch, bool ta, bool tb, b
   const long long nt = p0.M / N_BM;
   const unsigned G = (unsigned)(nt < num_cus ? ((nt + 7) / 8) * 8 : num_cus);
   GemmP p = p0;
+  const LnP q = {nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0.f};
 #define LAUNCH_N(EP_, BI_)                                                                          \
   do {                                                                                              \
     PERO_LDS_ATTR((gemm_bf16_n512<EP_, BI_>), N_LDS_BYTES);                                          \
-    hipLaunchKernelGGL((gemm_bf16_n512<EP_, BI_>), dim3(G), dim3(512), N_LDS_BYTES, st, p);          \
+    hipLaunchKernelGGL((gemm_bf16_n512<EP_, BI_>), dim3(G), dim3(512), N_LDS_BYTES, st, p, q);       \
   } while (0)
   if (p0.resid) { if (p0.bias) LAUNCH_N(EP_RESID, true); else LAUNCH_N(EP_RESID, false); }
   else { if (p0.bias) LAUNCH_N(EP_PLAIN, true); else LAUNCH_N(EP_PLAIN, false); }
+  return true;
+}
+// y = A W^T + bias + resid (bf16, stored), t = LayerNorm(y) * gamma + beta (bf16), mean / rstd of every row: one launch on the row-complete
+// tile.  false: the shape does not take it (N must be 512).
+bool pero_launch_gemm_n512_ln(const GemmP& p0, void* t, long long ldt, float* mean, float* rstd, const float* gamma, const float* beta, float eps,
+                              hipStream_t st) {
+  if (p0.N != 512 || p0.M % N_BM || p0.K % E_BK || p0.K < 3 * E_BK || !p0.resid || !t || !mean || !rstd || !gamma || !beta) return false;
+  if (p0.lda >= (1LL << 22) || p0.ldb >= (1LL << 22) || p0.ldc >= (1LL << 22) || p0.ldr >= (1LL << 22) || ldt >= (1LL << 22)) return false;
+  int num_cus = (pero_num_cus() / 8) * 8;
+  if (num_cus < 8) num_cus = 8;
+  const long long nt = p0.M / N_BM;
+  const unsigned G = (unsigned)(nt < num_cus ? ((nt + 7) / 8) * 8 : num_cus);
+  GemmP p = p0;
+  const LnP q = {t, ldt, mean, rstd, gamma, beta, eps};
+  if (p0.bias) LAUNCH_N(EP_RESID_LN, true); else LAUNCH_N(EP_RESID_LN, false);
 #undef LAUNCH_N
   return true;
 }

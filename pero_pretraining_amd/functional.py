@@ -192,6 +192,22 @@ def attention_bwd(qkv, p, dout, n, s, h):
 FUSED_ATTENTION = True  # bf16, head_dim 128, S % 128 == 0: flash-style HIP kernels; else batched GEMM + softmax
 
 
+FUSE_LN_FWD_MAX_K = 4096  # Linear + residual + LayerNorm as ONE launch (csrc/gemm_e.hip gemm_bf16_n512, pero_gemm_resid_layernorm) for reductions up to this
+                          # length: at K = 512 (out-projection) the fused launch takes 509 us against 352 + 195 for the pair (524 288 rows), at
+                          # K = 2048 (linear2) 1 133 against 931 + 190 - the row-complete tile runs 5 % behind the 256 x 256 one there; in the
+                          # 2048-line step: never 147.7 ms, out-projection only 147.0, both 146.8.  0: never
+
+
+def linear_resid_ln_fwd(x, lin_w, lin_b, resid, norm, dtype):
+    """y = x @ W^T + b + resid ; t, mean, rstd = LayerNorm(y): fused where the shape and the reduction length allow, else the pair."""
+    if (dtype == torch.bfloat16 and FUSE_LN_FWD_MAX_K and x.shape[1] <= FUSE_LN_FWD_MAX_K and lin_b is not None and
+            ops.gemm_resid_layernorm_ok(x, lowp.weight(lin_w, dtype), resid)):
+        return ops.gemm_resid_layernorm(x, lowp.weight(lin_w, dtype), lin_b.detach(), resid, norm.weight.detach(), norm.bias.detach(), norm.eps)
+    y = linear_fwd(x, lin_w, lin_b, dtype, residual=resid)
+    t, mean, rstd = ops.layernorm_fwd(y, norm.weight.detach(), norm.bias.detach(), norm.eps)
+    return y, t, mean, rstd
+
+
 def layer_fwd(t, L, n, s, h, dtype, save):
     at = L.self_attn
     qkv = linear_fwd(t, at.in_proj_weight, at.in_proj_bias, dtype)
@@ -199,15 +215,13 @@ def layer_fwd(t, L, n, s, h, dtype, save):
         a, p = ops.attention_fwd_fused(qkv, n, s, h)   # p = base-2 log-sum-exp rows (N*h, S)
     else:
         a, p = attention_fwd(qkv, n, s, h)             # p = probabilities (N*h, S, S)
-    y1 = linear_fwd(a, at.out_proj.weight, at.out_proj.bias, dtype, residual=t)
-    t1, mean1, rstd1 = ops.layernorm_fwd(y1, L.norm1.weight.detach(), L.norm1.bias.detach(), L.norm1.eps)
+    y1, t1, mean1, rstd1 = linear_resid_ln_fwd(a, at.out_proj.weight, at.out_proj.bias, t, L.norm1, dtype)
     bits = None
     if save and DX_ON_WT and relu_bits_ok(t1.shape[0], L.linear1.weight.shape[0], t1.shape[1], dtype) and \
             relu_bits_ok(t1.shape[0], L.linear1.weight.shape[0], L.linear2.weight.shape[0], dtype):
         bits = torch.empty((t1.shape[0], L.linear1.weight.shape[0] // 8), device=t1.device, dtype=torch.uint8)
     hdn = linear_fwd(t1, L.linear1.weight, L.linear1.bias, dtype, relu=True, relu_bits=bits)
-    y2 = linear_fwd(hdn, L.linear2.weight, L.linear2.bias, dtype, residual=t1)
-    t2, mean2, rstd2 = ops.layernorm_fwd(y2, L.norm2.weight.detach(), L.norm2.bias.detach(), L.norm2.eps)
+    y2, t2, mean2, rstd2 = linear_resid_ln_fwd(hdn, L.linear2.weight, L.linear2.bias, t1, L.norm2, dtype)
     saved = (t, qkv, p, a, y1, mean1, rstd1, t1, hdn, y2, mean2, rstd2, bits) if save else None
     return t2, saved
 

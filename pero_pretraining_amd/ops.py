@@ -132,6 +132,26 @@ def layernorm_fwd(x, gamma, beta, eps, pe=None, offsets=None, S=1):
     return y, mean, rstd
 
 
+def gemm_resid_layernorm_ok(a, w, residual):
+    """Shapes the fused Linear + residual + LayerNorm launch takes (csrc/gemm_e.hip gemm_bf16_n512: bf16, 512 output columns)."""
+    return (a.dtype == torch.bfloat16 and a.dim() == 2 and w.dim() == 2 and w.shape[0] == 512 and a.shape[0] % 128 == 0 and a.shape[1] % 64 == 0 and
+            a.shape[1] >= 192 and a.shape[1] == w.shape[1] and residual is not None and residual.shape == (a.shape[0], 512) and
+            a.stride(1) == 1 and w.stride(1) == 1 and residual.stride(1) == 1 and a.stride(0) % 8 == 0 and w.stride(0) % 8 == 0 and residual.stride(0) % 8 == 0)
+
+
+def gemm_resid_layernorm(a, w, bias, residual, gamma, beta, eps):
+    """y = a @ w^T + bias + residual (bf16, stored), t = LayerNorm(y) * gamma + beta, mean, rstd - ONE launch (pero_gemm_resid_layernorm)."""
+    _req_cuda(a)
+    M, K = a.shape
+    y = torch.empty((M, 512), device=a.device, dtype=torch.bfloat16)
+    t = torch.empty((M, 512), device=a.device, dtype=torch.bfloat16)
+    mean = torch.empty(M, device=a.device, dtype=torch.float32)
+    rstd = torch.empty(M, device=a.device, dtype=torch.float32)
+    call("pero_gemm_resid_layernorm", ptr(a), ptr(w), ptr(bias), ptr(residual), ptr(gamma), ptr(beta), ptr(y), ptr(t), ptr(mean), ptr(rstd),
+         M, 512, K, a.stride(0), w.stride(0), y.stride(0), residual.stride(0), t.stride(0), float(eps), stream())
+    return y, t, mean, rstd
+
+
 def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, dxsum=None):
     rows, d = x.shape
     dx = torch.empty_like(x)

@@ -218,3 +218,37 @@ def test_row_complete_tile_gives_the_bits_of_the_256x256_tile(e256, M, K):
                 assert torch.equal(ops.gemm(x, w, **kw), got), kw
     finally:
         L.pero_set_option(b"gemm_nw", 0)
+
+
+@pytest.mark.parametrize("M,K", [(1024, 192), (2176, 512), (131072, 2048)])
+def test_fused_linear_residual_layernorm(e256, M, K):
+    """pero_gemm_resid_layernorm (gemm_bf16_n512 with the LayerNorm epilogue): y = the bits of the residual product, mean / rstd / t = what
+    pero_layernorm_fwd computes from those rows (two-pass variance over the ROUNDED rows; other summation order: 1e-6 on the statistics, at
+    most one bf16 step on a few t per million), repeatable; with and without the Linear's bias."""
+    ops = e256
+    from pero_pretraining_amd import _lib
+    L = _lib.lib()
+    torch.manual_seed(13)
+    x = (torch.randn(M, K, device="cuda") * 0.5).bfloat16()
+    w = (torch.randn(512, K, device="cuda") * 0.05).bfloat16()
+    bias = torch.randn(512, device="cuda")
+    res = torch.randn(M, 512, device="cuda").bfloat16()
+    gamma = torch.rand(512, device="cuda") + 0.5
+    beta = torch.randn(512, device="cuda") * 0.1
+    assert ops.gemm_resid_layernorm_ok(x, w, res)
+    for b in (bias, None):
+        try:
+            L.pero_set_option(b"gemm_nw", 1)      # the unfused pair with the product on the same tile kernel (it takes M % 128 == 0)
+            y0 = ops.gemm(x, w, bias=b, residual=res)
+        finally:
+            L.pero_set_option(b"gemm_nw", 0)
+        t0, m0, r0 = ops.layernorm_fwd(y0, gamma, beta, 1e-5)
+        y, t, mean, rstd = ops.gemm_resid_layernorm(x, w, b, res, gamma, beta, 1e-5)
+        assert torch.equal(y, y0)
+        assert float((mean - m0).abs().max()) <= 1e-6 and float(((rstd - r0) / r0).abs().max()) <= 1e-5
+        d = (t.float() - t0.float()).abs()
+        assert float(d.max()) <= 2 ** -7 * float(t0.float().abs().max())          # one bf16 step at the top of the range
+        assert int((d > 0).sum()) <= 1e-4 * t.numel()
+        for _ in range(3):
+            again = ops.gemm_resid_layernorm(x, w, b, res, gamma, beta, 1e-5)
+            assert all(torch.equal(a, c) for a, c in zip(again, (y, t, mean, rstd)))
