@@ -247,7 +247,8 @@ def gemm_roofline(per, nsteps, step_seconds, traffic):
     ach = fsum / tsum / 1e12
     return {"bound": "mfma",
             "kernel": "bf16 MFMA tile GEMM gemm_bf16_e256 (eight-phase persistent 256x256x64: forward, input gradients with fused "
-                      "epilogues, split-K weight gradients)",
+                      "epilogues, split-K weight gradients) + its row-complete 128x512 form gemm_bf16_n512 (out-projection / linear2 with the "
+                      "residual LayerNorm in the epilogue: the product's flops over the whole launch)",
             "achieved": round(ach, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4),
             "traffic": traffic, "launches_per_step": nl // nsteps, "avg_launch_us": round(tsum / nl * 1e6, 2),
             "gflop_per_launch": round(fsum / nl / 1e9, 3),

@@ -68,7 +68,8 @@ int pero_abi_version(void);
  * with software-pipelined inline-asm operand reads; 0: the compiler-scheduled loops - same bits), "attn_lh" (0; 1: S = 256 backward as one persistent workgroup
  * per CU and (line, head) - same bits, not faster), "splitk_workspace" (1: the split-K
  * products of the eight-phase kernel leave partial tiles in the caller's `workspace`, summed in slice order by a second kernel - deterministic;
- * 0: f32 atomics even when a workspace is passed), "splitk_table" (1: unaligned slice counts hand their work items out XCD by XCD).  Process-wide; not
+ * 0: f32 atomics even when a workspace is passed), "splitk_table" (1: unaligned slice counts hand their work items out XCD by XCD), "gemm_nw" (0; 1: stored
+ * N = 512 products with a bias / residual epilogue run on the row-complete 128 x 512 tile that pero_gemm_resid_layernorm uses - same bits).  Process-wide; not
  * meant to be changed while products are in flight. */
 int pero_set_option(const char* name, int value);
 
