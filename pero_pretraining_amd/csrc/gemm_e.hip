@@ -1064,6 +1064,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_n512(GemmP p, LnP q) {
       (void)xw16; (void)xr16; (void)xsw; (void)xsr; (void)xw32; (void)xr32; (void)gvo; (void)cq;
       const ei4v crs = ersrc((bf16raw*)p.C + tm0 * p.ldc, (unsigned)(128 * p.ldc * 2));
       const int cpitch = (int)(p.ldc * 2);
+      unsigned ones2 = 0x3f803f80u;   // the bf16 pair (1, 1), in a register the compiler cannot fold into an inline constant (see the gate epilogue of gemm_bf16_e256)
+      asm volatile("" : "+s"(ones2));
+      (void)ones2;
       eu4v yk[2][4][2];   // LN: the packed rows of y, kept for the statistics and the normalisation (the accumulators die as they are consumed)
       float rsum[2][4];   // LN: this lane's share of the row sums (rows 64 ha + 16 i + er, its 16 columns)
       eu4v gb[8];         // LN: gamma / beta of the lane's 16 columns: [hb][half] then + 4
@@ -1126,9 +1129,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_n512(GemmP p, LnP q) {
                 o[ii][hb][0] = pack2bf(v[0], v[1]); o[ii][hb][1] = pack2bf(v[2], v[3]); o[ii][hb][2] = pack2bf(v[4], v[5]); o[ii][hb][3] = pack2bf(v[6], v[7]);
                 if (LN) {
                   yk[ha][i][hb] = o[ii][hb];
-                  float sacc = hb ? rsum[ha][i] : 0.f;   // the LayerNorm kernel sums the ROUNDED values (layernorm_fwd4_k)
+                  float sacc = hb ? rsum[ha][i] : 0.f;   // the LayerNorm kernel sums the ROUNDED values (layernorm_fwd4_k); (x, y) . (1, 1): one instruction per pair
 #pragma unroll
-                  for (int e = 0; e < 4; e++) { sacc += __uint_as_float(o[ii][hb][e] << 16); sacc += __uint_as_float(o[ii][hb][e] & 0xffff0000u); }
+                  for (int e = 0; e < 4; e++) sacc = edot2(o[ii][hb][e], ones2, sacc);
                   rsum[ha][i] = sacc;
                 }
               } else {
@@ -1183,6 +1186,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_n512(GemmP p, LnP q) {
         };
         if (!(N_DBG & 8)) exchange(rsum, 0);
         float mu[2][4], qs[2][4];
+        float xc[2][4][2][8];   // the centred values: unpacked and centred ONCE, used by the variance and by the normalisation (the accumulators are dead: 128 registers)
 #pragma unroll
         for (int ha = 0; ha < 2; ha++)
 #pragma unroll
@@ -1194,6 +1198,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_n512(GemmP p, LnP q) {
 #pragma unroll
               for (int e = 0; e < 4; e++) {
                 const float t0 = __uint_as_float(yk[ha][i][hb][e] << 16) - mu[ha][i], t1 = __uint_as_float(yk[ha][i][hb][e] & 0xffff0000u) - mu[ha][i];
+                xc[ha][i][hb][2 * e] = t0; xc[ha][i][hb][2 * e + 1] = t1;
                 a += t0 * t0; a += t1 * t1;
               }
             qs[ha][i] = a;
@@ -1220,8 +1225,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_n512(GemmP p, LnP q) {
               for (int e = 0; e < 4; e++) {
                 const float g0 = (N_DBG & 1) ? 1.f : __uint_as_float(gb[2 * hb + (e >> 1)][2 * (e & 1)]), g1 = (N_DBG & 1) ? 1.f : __uint_as_float(gb[2 * hb + (e >> 1)][2 * (e & 1) + 1]);
                 const float b0 = (N_DBG & 1) ? 0.f : __uint_as_float(gb[4 + 2 * hb + (e >> 1)][2 * (e & 1)]), b1 = (N_DBG & 1) ? 0.f : __uint_as_float(gb[4 + 2 * hb + (e >> 1)][2 * (e & 1) + 1]);
-                const float v0 = __uint_as_float(yk[ha][i][hb][e] << 16), v1 = __uint_as_float(yk[ha][i][hb][e] & 0xffff0000u);
-                ot[e] = (N_DBG & 4) ? yk[ha][i][hb][e] : pack2bf((v0 - mu[ha][i]) * rs * g0 + b0, (v1 - mu[ha][i]) * rs * g1 + b1);
+                ot[e] = (N_DBG & 4) ? yk[ha][i][hb][e] : pack2bf(xc[ha][i][hb][2 * e] * rs * g0 + b0, xc[ha][i][hb][2 * e + 1] * rs * g1 + b1);
               }
               const int so = (64 * ha + 16 * i) * tpitch;
               if (hb) E_BSTORE16(ot, tvo, trs, so, 64); else E_BSTORE16(ot, tvo, trs, so, 0);
