@@ -246,3 +246,24 @@ def test_masked_head_mode_is_validated_on_the_host():
     model.head_rows = "some"
     with pytest.raises(ValueError, match="Unknown head_rows"):
         model(torch.zeros(1, 3, 40, 16), None, None)
+
+
+def test_inline_asm_vector_memory_of_the_tile_gemm_passes_the_isa_lint(tmp_path):
+    """tools/check_async_loads.py on the ISA of csrc/gemm_e.hip (hipcc cross-compiles without a GPU): no instruction touches the destination of
+    an inline-asm load before a counted s_waitcnt has retired it, and no vector-memory instruction reads an SGPR that a v_readlane_b32 (a
+    restored spill) wrote fewer than five wait states earlier - the compiler pads neither for instructions inside an asm string (round 3: the
+    LayerNorm epilogue's stores took stale row offsets; one store of the production ReLU-bits kernel had the same exposure)."""
+    import shutil
+    import subprocess
+    import sys
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "gemm_e.s")
+    subprocess.run([hipcc, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-munsafe-fp-atomics", "-ffp-contract=off", "-Wno-unused-value",
+                    "-S", "--cuda-device-only", os.path.join(root, "pero_pretraining_amd", "csrc", "gemm_e.hip"), "-o", out],
+                   check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_async_loads.py"), out, "gemm_bf16"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert "gemm_bf16_n512" in r.stdout and "gemm_bf16_e256" in r.stdout
