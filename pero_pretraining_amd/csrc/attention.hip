@@ -1043,8 +1043,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_pair_k(const bf16raw* qkv, co
 #define LH_LDS_BYTES (LH_PART + 8 * 1536)   // 160 768 B of the CU's 163 840
 
 // LDS-DMA, 16 (4) bytes per lane: global address = sbase + voff, LDS address = dst + 16 (4) * lane
+// Every asm vector-memory instruction below that takes an SGPR base opens with wait states: a v_readlane_b32 / v_readfirstlane_b32 that has
+// just (re)written the SGPR - a restored spill - needs five of them before a vector-memory instruction reads it, and the compiler pads that
+// hazard for its own instructions only (gemm_e.hip's E_BSTORE16 took stale row offsets that way in round 3; tools/check_async_loads.py
+// checks the ISA of these kernels too: tests/test_cabi_and_host.py).  With the s_mov the LDS-DMA forms have s_nop 3 + 1.
 __device__ __forceinline__ void lh_dma16(const void* sbase, unsigned voff, unsigned dst) {
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" :: "s"(sbase), "v"(voff), "s"(dst) : "memory", "m0");
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %1, %0" :: "s"(sbase), "v"(voff), "s"(dst) : "memory", "m0");
 }
 __device__ __forceinline__ void lh_dma4(const float* addr, unsigned dst) {
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" :: "v"(addr), "s"(dst) : "memory", "m0");
@@ -1052,19 +1056,19 @@ __device__ __forceinline__ void lh_dma4(const float* addr, unsigned dst) {
 template <int IMM, typename T>
 __device__ __forceinline__ void lh_gload16(T& d, const void* sbase, unsigned voff) {
   static_assert(sizeof(T) == 16 && IMM >= 0 && IMM < 4096, "global_load_dwordx4");
-  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(d) : "v"(voff), "s"(sbase), "i"(IMM) : "memory");
+  asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(d) : "v"(voff), "s"(sbase), "i"(IMM) : "memory");
 }
 __device__ __forceinline__ void lh_gload4(float& d, const void* sbase, unsigned voff) {
-  asm volatile("global_load_dword %0, %1, %2" : "=v"(d) : "v"(voff), "s"(sbase) : "memory");
+  asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "=v"(d) : "v"(voff), "s"(sbase) : "memory");
 }
 // (the trailing wait states: the data registers are rewritten right behind the store - see E_BSTORE16 in gemm_e.hip)
 template <int IMM, typename T>
 __device__ __forceinline__ void lh_gstore16(const T& v, void* sbase, unsigned voff) {
   static_assert(sizeof(T) == 16 && IMM >= 0 && IMM < 4096, "global_store_dwordx4");
-  asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 2" :: "v"(voff), "v"(v), "s"(sbase), "i"(IMM) : "memory");
+  asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 2" :: "v"(voff), "v"(v), "s"(sbase), "i"(IMM) : "memory");
 }
 __device__ __forceinline__ void lh_gstore4(float v, void* sbase, unsigned voff) {
-  asm volatile("global_store_dword %0, %1, %2\n\ts_nop 2" :: "v"(voff), "v"(v), "s"(sbase) : "memory");
+  asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2\n\ts_nop 2" :: "v"(voff), "v"(v), "s"(sbase) : "memory");
 }
 template <int N>
 __device__ __forceinline__ void lh_wait_vm() {

@@ -267,3 +267,28 @@ def test_inline_asm_vector_memory_of_the_tile_gemm_passes_the_isa_lint(tmp_path)
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_async_loads.py"), out, "gemm_bf16"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:]
     assert "gemm_bf16_n512" in r.stdout and "gemm_bf16_e256" in r.stdout
+
+
+def test_inline_asm_vector_memory_of_the_attention_kernels_passes_the_sgpr_lint(tmp_path):
+    """The same SGPR hazard check on csrc/attention.hip (round-3 advice): its asm global_load_dword* / global_store_dword* / global_load_lds
+    statements take an SGPR base, the kernels hold 20-38 v_readlane / v_readfirstlane each, and nothing but the `s_nop`s inside the asm strings
+    keeps a restored SGPR five wait states away from the vector-memory instruction that reads it.  (Only the SGPR check: the in-flight-register
+    check models straight-line code and the attention loops are compiler-scheduled.)"""
+    import shutil
+    import subprocess
+    import sys
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "attention.s")
+    subprocess.run([hipcc, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-munsafe-fp-atomics", "-ffp-contract=off", "-Wno-unused-value",
+                    "-S", "--cuda-device-only", os.path.join(root, "pero_pretraining_amd", "csrc", "attention.hip"), "-o", out],
+                   check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_async_loads.py"), out, "attn", "--sgpr-only"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert "attn_fwd_p_k" in r.stdout and "attn_bwd_pair_k" in r.stdout and "attn_bwd_lh_k" in r.stdout
+    src = open(os.path.join(root, "pero_pretraining_amd", "csrc", "attention.hip")).read()
+    import re
+    for m in re.finditer(r'asm volatile\("([^"]*(?:global_load_dword|global_store_dword)[^"]*)"', src):
+        assert m.group(1).startswith("s_nop 4"), "asm vector-memory statement without leading wait states: " + m.group(1)[:60]

@@ -4,7 +4,9 @@ kernel's ISA in program order with the in-order vmcnt queue (loads, stores, LDS-
 OVERWRITES the destination registers of a load that no s_waitcnt has retired yet - the compiler is free to copy or re-home the result of an
 asm load before the wait it cannot see (it did, under register pressure, in the first LayerNorm epilogue: values of not-yet-arrived loads
 were copied and the arriving data later overwrote live registers).  Straight-line approximation: branches are ignored.
-usage: python tools/check_async_loads.py <file.s> [kernel-name-substring]"""
+usage: python tools/check_async_loads.py <file.s> [kernel-name-substring] [--sgpr-only]
+--sgpr-only: only the second check (vector-memory instruction reading an SGPR fewer than five wait states after a vector-ALU write of it): the
+first one models straight-line code and gives false positives on compiler-scheduled kernels with loops (attention.hip)."""
 import re, sys
 
 def regs(tok):
@@ -15,8 +17,10 @@ def regs(tok):
     return {int(m.group(1))} if m else set()
 
 def main():
-    lines = open(sys.argv[1]).read().split('\n')
-    pat = sys.argv[2] if len(sys.argv) > 2 else ''
+    sgpr_only = '--sgpr-only' in sys.argv
+    argv = [a for a in sys.argv if a != '--sgpr-only']
+    lines = open(argv[1]).read().split('\n')
+    pat = argv[2] if len(argv) > 2 else ''
     names = [m.group(1) for l in lines for m in [re.match(r'^(_Z\w+):', l)] if m and pat in l]
     total = 0
     for nm in names:
@@ -37,7 +41,7 @@ def main():
             l2 = l.strip()
             if l2 and not l2.startswith((';', '.')) and not l2.endswith(':'):
                 pp = re.split(r'[ ,]+', l2)
-                if pp[0].startswith(('buffer_load', 'buffer_store', 'global_load_lds', 'buffer_atomic')):
+                if pp[0].startswith(('buffer_load', 'buffer_store', 'global_load_lds', 'buffer_atomic', 'global_load_dword', 'global_store_dword', 'global_atomic')):
                     need = set().union(*[sregs(t) for t in pp[1:]])
                     ws = 0
                     for w, wr in reversed(hist):
@@ -63,7 +67,7 @@ def main():
             toks = [t for t in parts[1:]]
             used = set().union(*[regs(t) for t in toks]) if toks else set()
             pending = set().union(*[q[1] for q in queue]) if queue else set()
-            if used & pending and not op.startswith('s_waitcnt'):
+            if used & pending and not op.startswith('s_waitcnt') and not sgpr_only:
                 bad = [q[2] for q in queue if q[1] & used]
                 print(f"{nm[:60]}: `{l}` touches registers of a load still in flight: {bad[0][:70]}")
                 issues += 1
