@@ -115,7 +115,9 @@ int64_t pero_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K, int64_t batch
  * reads it), T = LayerNorm(Y) * gamma + beta computed from the rounded rows of Y exactly as pero_layernorm_fwd does, mean / rstd f32 per row.
  * Replaces the pair (Linear with the residual add, torch.nn.LayerNorm) of TransformerEncoderLayer's post-norm blocks
  * (x = norm1(x + out_proj(attn)), x = norm2(x + linear2(...)): models/transformers.py:36-43) - the LayerNorm's read of Y goes away.
- * bias may be null.  PERO_E_INVALID for other shapes: the caller falls back to pero_gemm + pero_layernorm_fwd. */
+ * bias may be null.  PERO_E_INVALID for other shapes: the caller falls back to pero_gemm + pero_layernorm_fwd.
+ * Y may be null (round 4): the pre-norm rows are then not stored at all - a backward pass through pero_layernorm_bwd_out needs T and rstd
+ * only (16 fewer 16-byte stores per lane and tile, a quarter of the launch's HBM traffic at K = 512). */
 int pero_gemm_resid_layernorm(const void* A, const void* W, const float* bias, const void* R, const float* gamma, const float* beta,
                               void* Y, void* T, float* mean, float* rstd, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw,
                               int64_t ldy, int64_t ldr, int64_t ldt, float eps, void* stream);
@@ -134,6 +136,15 @@ int pero_layernorm_fwd(const void* x, const float* gamma, const float* beta, con
 int pero_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
                        void* dx, float* dgamma, float* dbeta, float* dxsum, float* work, int64_t rows, int64_t d,
                        int dtype, void* stream);
+/* The same backward from the layer's OUTPUT t = xhat * gamma + beta instead of its input rows: xhat = (t - beta) / gamma, so the
+ * forward pass keeps t (which the next Linear reads anyway) and rstd, not x and mean ("memory-efficient" LayerNorm; torch.nn.LayerNorm
+ * saves its input - models/transformers.py:28,36-43 - the gradient is the same function of the same quantities).  In f32 the two forms
+ * agree to rounding; in bf16 t carries the 2^-9 relative rounding x carried before.  A column with gamma == 0 exactly has no xhat left in
+ * t: it is taken as 0 (that column's gamma gradient and its -xhat * c2 share of dx are lost, nothing is NaN, other columns are exact) -
+ * keep pero_layernorm_bwd where a scale can be exactly zero.  Same accumulation semantics and workspace as above. */
+int pero_layernorm_bwd_out(const void* dy, const void* t, const float* rstd, const float* gamma, const float* beta,
+                           void* dx, float* dgamma, float* dbeta, float* dxsum, float* work, int64_t rows, int64_t d,
+                           int dtype, void* stream);
 
 /* ---- softmax over the last dim (attention probabilities; torch SDPA inside
  * TransformerEncoderLayer._sa_block, models/transformers.py:86) ---------------------------------------

@@ -32,6 +32,7 @@ SIGNATURES = {
                   _i64, _i64, _i64, _i64, _i64, _i64, _f32, _i32, _i32, _i32, _i32, _vp, _i64, _vp],
     "pero_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _f32, _i32, _vp],
     "pero_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp],
+    "pero_layernorm_bwd_out": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp],
     "pero_attention_fwd": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp],
     "pero_attention_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp],
     "pero_softmax_fwd": [_vp, _vp, _i64, _i64, _f32, _i32, _vp],

@@ -415,14 +415,14 @@ static bool splitk_takes_e256(int64_t M, int64_t N, int64_t K, int flags) {
 extern "C" int pero_gemm_resid_layernorm(const void* A, const void* W, const float* bias, const void* R, const float* gamma, const float* beta,
                                          void* Y, void* T, float* mean, float* rstd, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw,
                                          int64_t ldy, int64_t ldr, int64_t ldt, float eps, void* stream) {
-  PERO_REQUIRE(A && W && R && gamma && beta && Y && T && mean && rstd, "pero_gemm_resid_layernorm: null pointer");
-  PERO_REQUIRE(N == 512 && M > 0 && M % 128 == 0 && K % 64 == 0 && K >= 192 && lda % 8 == 0 && ldw % 8 == 0 && ldy % 8 == 0 && ldr % 8 == 0 &&
-               ldt % 8 == 0 && aligned16(A) && aligned16(W) && aligned16(R) && aligned16(Y) && aligned16(T) && aligned16(gamma) && aligned16(beta) &&
+  PERO_REQUIRE(A && W && R && gamma && beta && T && mean && rstd, "pero_gemm_resid_layernorm: null pointer");   // Y may be null: not stored
+  PERO_REQUIRE(N == 512 && M > 0 && M % 128 == 0 && K % 64 == 0 && K >= 192 && lda % 8 == 0 && ldw % 8 == 0 && (!Y || ldy % 8 == 0) && ldr % 8 == 0 &&
+               ldt % 8 == 0 && aligned16(A) && aligned16(W) && aligned16(R) && (!Y || aligned16(Y)) && aligned16(T) && aligned16(gamma) && aligned16(beta) &&
                (!bias || aligned16(bias)),
                "pero_gemm_resid_layernorm: bf16, N = 512, M %% 128 == 0, K %% 64 == 0, K >= 192, 16-byte aligned rows");
   GemmP p;
   p.A = A; p.B = W; p.C = Y; p.bias = bias; p.resid = R; p.gate = nullptr;
-  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldw; p.ldc = ldy; p.ldr = ldr; p.ldg = 0;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldw; p.ldc = Y ? ldy : 512; p.ldr = ldr; p.ldg = 0;
   p.sAo = p.sAi = p.sBo = p.sBi = p.sCo = p.sCi = 0;
   p.binner = 1; p.alpha = 1.0f; p.flags = 0; p.kchunk = K;
   PERO_REQUIRE(pero_launch_gemm_n512_ln(p, T, ldt, mean, rstd, gamma, beta, eps, (hipStream_t)stream), "pero_gemm_resid_layernorm: shape not taken");

@@ -60,6 +60,7 @@
 #define EP_ROWDOT 6      // `bias`[m][n / 128] += row dots of the stored result with `gate` (bf16 rows of C's shape)
 #define EP_SPLITK 7      // f32 C += partial product of ONE k-slice (atomics): one work item (tile, k-slice) per workgroup, not persistent
 #define EP_RESID_LN 8    // (gemm_bf16_n512 only) bias, + residual -> y stored; LayerNorm of the stored rows -> t, mean, rstd (LnP)
+#define EP_RESID_LN_T 9  // the same without the stores of y (the backward reads t: pero_layernorm_bwd_out): the epilogue's counted waits differ
 // second argument of gemm_bf16_n512: what the LayerNorm epilogue writes and reads beside GemmP
 struct LnP { void* t; long long ldt; float* mean; float* rstd; const float* gamma; const float* beta; float eps; };
 
@@ -851,13 +852,14 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p, int ks) {
 template <int EPI, bool BIAS>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_n512(GemmP p, LnP q) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  static_assert(EPI == EP_PLAIN || EPI == EP_RESID || EPI == EP_RESID_LN, "the row-complete tile has the plain, the residual and the residual + LayerNorm epilogue");
-  constexpr bool LN = EPI == EP_RESID_LN;
+  static_assert(EPI == EP_PLAIN || EPI == EP_RESID || EPI == EP_RESID_LN || EPI == EP_RESID_LN_T, "the row-complete tile has the plain, the residual and the residual + LayerNorm epilogue");
+  constexpr bool LN = EPI == EP_RESID_LN || EPI == EP_RESID_LN_T;
+  constexpr bool STORE_Y = EPI != EP_RESID_LN_T;
   constexpr bool RES = EPI == EP_RESID || LN;
   constexpr int LB = BIAS ? 4 : 0;                        // bias side loads (16 B per lane each)
   constexpr int L0 = LB + (RES ? 8 : 0);                  // side loads issued in phase 4 of the last K-tile: bias + residual rows 0-63
   constexpr int L1 = RES ? 8 : 0;                         // residual rows 64-127, issued halfway through rows 0-63
-  constexpr int SH = 8;                                   // stores per half of the epilogue
+  constexpr int SH = STORE_Y ? 8 : 0;                     // stores per half of the epilogue
   constexpr int LNX = LN ? 8 + 2 + 16 : 0;                // LayerNorm: gamma / beta loads, mean / rstd stores, the 16 stores of t
   constexpr int EPO = L1 + 2 * SH + LNX;                  // vector-memory operations of an epilogue behind its phase-4 side loads
   constexpr int cap63 = 63;                               // s_waitcnt vmcnt takes six bits: a larger count only asks for more than needed
@@ -1150,6 +1152,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_n512(GemmP p, LnP q) {
 #pragma unroll
             for (int hb = 0; hb < 2; hb++) {
               eu4v& ou = o[ii][hb];
+              if (!STORE_Y) continue;
               if (hb) E_BSTORE16(ou, cvo, crs, so, 64); else E_BSTORE16(ou, cvo, crs, so, 0);
             }
           }
@@ -1274,14 +1277,15 @@ bool pero_launch_gemm_n512(const GemmP& p0, long long batch, bool ta, bool tb, b
 bool pero_launch_gemm_n512_ln(const GemmP& p0, void* t, long long ldt, float* mean, float* rstd, const float* gamma, const float* beta, float eps,
                               hipStream_t st) {
   if (p0.N != 512 || p0.M % N_BM || p0.K % E_BK || p0.K < 3 * E_BK || !p0.resid || !t || !mean || !rstd || !gamma || !beta) return false;
-  if (p0.lda >= (1LL << 22) || p0.ldb >= (1LL << 22) || p0.ldc >= (1LL << 22) || p0.ldr >= (1LL << 22) || ldt >= (1LL << 22)) return false;
+  if (p0.lda >= (1LL << 22) || p0.ldb >= (1LL << 22) || (p0.C && p0.ldc >= (1LL << 22)) || p0.ldr >= (1LL << 22) || ldt >= (1LL << 22)) return false;
   int num_cus = (pero_num_cus() / 8) * 8;
   if (num_cus < 8) num_cus = 8;
   const long long nt = p0.M / N_BM;
   const unsigned G = (unsigned)(nt < num_cus ? ((nt + 7) / 8) * 8 : num_cus);
   GemmP p = p0;
   const LnP q = {t, ldt, mean, rstd, gamma, beta, eps};
-  if (p0.bias) LAUNCH_N(EP_RESID_LN, true); else LAUNCH_N(EP_RESID_LN, false);
+  if (!p0.C) { if (p0.bias) LAUNCH_N(EP_RESID_LN_T, true); else LAUNCH_N(EP_RESID_LN_T, false); }   // y not stored
+  else if (p0.bias) LAUNCH_N(EP_RESID_LN, true); else LAUNCH_N(EP_RESID_LN, false);
 #undef LAUNCH_N
   return true;
 }

@@ -126,19 +126,27 @@ __global__ __launch_bounds__(256) void layernorm_fwd4_k(const bf16raw* x, const 
 
 // LayerNorm backward: dx per row; dgamma / dbeta / column sums of dx accumulated per lane over the rows
 // a wave visits, combined across the block's 4 waves through LDS, then one f32 atomic per column.
-template <typename T, int NCH>
+// FROM_OUT (round 4, "memory-efficient" LayerNorm): `x` is the layer's OUTPUT t = xhat * gamma + beta and `mean` is the BETA vector (per
+// column, not per row): xhat is recovered as (t - beta) / gamma, so the forward pass need not keep its input rows for the backward (in bf16
+// mode the stored t carries the same 2^-9 relative rounding the stored input rows had; columns with gamma == 0 lose their gamma gradient).
+template <typename T, int NCH, bool FROM_OUT>
 __global__ __launch_bounds__(256) void layernorm_bwd_k(const T* dy, const T* x, const float* mean, const float* rstd,
                                                        const float* gamma, T* dx, float* work, const float* dxsum,
                                                        long long rows, int d) {
   __shared__ float red[4][NCH * 512];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float ag[NCH][8], ab[NCH][8], ax[NCH][8], g[NCH][8];
+  float ag[NCH][8], ab[NCH][8], ax[NCH][8], g[NCH][8], bt[NCH][8], ig[NCH][8];
 #pragma unroll
   for (int c = 0; c < NCH; c++) {
     const int col = (c * 64 + lane) * 8;
 #pragma unroll
-    for (int e = 0; e < 8; e++) { ag[c][e] = 0.f; ab[c][e] = 0.f; ax[c][e] = 0.f; g[c][e] = 0.f; }
+    for (int e = 0; e < 8; e++) { ag[c][e] = 0.f; ab[c][e] = 0.f; ax[c][e] = 0.f; g[c][e] = 0.f; bt[c][e] = 0.f; ig[c][e] = 0.f; }
     if (col < d) load8<float>(gamma + col, g[c]);
+    if (FROM_OUT && col < d) {
+      load8<float>(mean + col, bt[c]);
+#pragma unroll
+      for (int e = 0; e < 8; e++) ig[c][e] = g[c][e] != 0.f ? 1.0f / g[c][e] : 0.f;
+    }
   }
   // two rows per iteration (independent loads and reduction chains in flight: the kernel is latency-, not bandwidth-bound
   // with one row per wave at a time)
@@ -150,7 +158,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_k(const T* dy, const T* x, 
 #pragma unroll
     for (int u = 0; u < 2; u++) {
       if (!has[u]) continue;
-      mu[u] = mean[rw[u]]; rs[u] = rstd[rw[u]];
+      mu[u] = FROM_OUT ? 0.f : mean[rw[u]]; rs[u] = rstd[rw[u]];
 #pragma unroll
       for (int c = 0; c < NCH; c++) {
         const int col = (c * 64 + lane) * 8;
@@ -160,7 +168,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_k(const T* dy, const T* x, 
           load8<T>(dy + rw[u] * d + col, dv);
 #pragma unroll
           for (int e = 0; e < 8; e++) {
-            xh[u][c][e] = (xv[e] - mu[u]) * rs[u];
+            xh[u][c][e] = FROM_OUT ? (xv[e] - bt[c][e]) * ig[c][e] : (xv[e] - mu[u]) * rs[u];
             gy[u][c][e] = dv[e] * g[c][e];
             s1[u] += gy[u][c][e];
             s2[u] += gy[u][c][e] * xh[u][c][e];
@@ -214,6 +222,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_k(const T* dy, const T* x, 
 // rows of the NEXT pair (x, dy: one 16-byte load each, mean, rstd) are requested before the current pair is reduced, so a
 // wave always has a pair of rows in flight (the plain loop issued its loads, waited, reduced, stored: latency-bound at 8
 // waves per CU).
+template <bool FROM_OUT>
 __global__ __launch_bounds__(256) void layernorm_bwd_pf_k(const bf16raw* dy, const bf16raw* x, const float* mean, const float* rstd,
                                                           const float* gamma, bf16raw* dx, float* work, const float* dxsum,
                                                           long long rows, int d) {
@@ -221,10 +230,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_pf_k(const bf16raw* dy, con
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = lane * 8;
   const bool act = col < d;
-  float ag[8], ab[8], ax[8], g[8];
+  float ag[8], ab[8], ax[8], g[8], bt[8], ig[8];
 #pragma unroll
-  for (int e = 0; e < 8; e++) { ag[e] = 0.f; ab[e] = 0.f; ax[e] = 0.f; g[e] = 0.f; }
+  for (int e = 0; e < 8; e++) { ag[e] = 0.f; ab[e] = 0.f; ax[e] = 0.f; g[e] = 0.f; bt[e] = 0.f; ig[e] = 0.f; }
   if (act) load8<float>(gamma + col, g);
+  if (FROM_OUT && act) {   // `mean` is the beta vector, `x` the LayerNorm output (see layernorm_bwd_k)
+    load8<float>(mean + col, bt);
+#pragma unroll
+    for (int e = 0; e < 8; e++) ig[e] = g[e] != 0.f ? 1.0f / g[e] : 0.f;
+  }
   const long long stride = (long long)gridDim.x * 4;
   long long row0 = (long long)blockIdx.x * 4 + wave;
   uint4 nx[2], nd[2];
@@ -235,7 +249,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_pf_k(const bf16raw* dy, con
     for (int u = 0; u < 2; u++) {
       const long long r = r0 + u * stride;
       if (r < rows) {
-        nmu[u] = mean[r]; nrs[u] = rstd[r];
+        nmu[u] = FROM_OUT ? 0.f : mean[r]; nrs[u] = rstd[r];
         if (act) { nx[u] = *(const uint4*)(x + r * d + col); nd[u] = *(const uint4*)(dy + r * d + col); }
       }
     }
@@ -255,7 +269,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_pf_k(const bf16raw* dy, con
       for (int e = 0; e < 8; e++) {
         const float xv = (e & 1) ? __uint_as_float(wx[e >> 1] & 0xffff0000u) : __uint_as_float(wx[e >> 1] << 16);
         const float dv = (e & 1) ? __uint_as_float(wd[e >> 1] & 0xffff0000u) : __uint_as_float(wd[e >> 1] << 16);
-        xh[u][e] = (xv - mu[u]) * rs[u];
+        xh[u][e] = FROM_OUT ? (xv - bt[e]) * ig[e] : (xv - mu[u]) * rs[u];
         gy[u][e] = dv * g[e];
         s1[u] += gy[u][e];
         s2[u] += gy[u][e] * xh[u][e];
@@ -329,16 +343,16 @@ static int ln_dispatch_fwd(const void* x, const float* gamma, const float* beta,
 #undef LN_F
   return 0;
 }
-template <typename T>
+template <typename T, bool FROM_OUT>
 static int ln_dispatch_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma, void* dx,
                            float* dgamma, float* dbeta, float* dxsum, float* work, int64_t rows, int64_t d, hipStream_t st) {
   long long blocks = (rows + 3) / 4;
   if (blocks > PERO_LN_BWD_BLOCKS) blocks = PERO_LN_BWD_BLOCKS;
   dim3 grid((unsigned)blocks), block(256);
   const int nch = (int)((d + 511) / 512);
-#define LN_B(N_) hipLaunchKernelGGL((layernorm_bwd_k<T, N_>), grid, block, 0, st, (const T*)dy, (const T*)x, mean, rstd, gamma, (T*)dx, work, dxsum, (long long)rows, (int)d)
+#define LN_B(N_) hipLaunchKernelGGL((layernorm_bwd_k<T, N_, FROM_OUT>), grid, block, 0, st, (const T*)dy, (const T*)x, mean, rstd, gamma, (T*)dx, work, dxsum, (long long)rows, (int)d)
   if (nch == 1 && sizeof(T) == 2)
-    hipLaunchKernelGGL(layernorm_bwd_pf_k, grid, block, 0, st, (const bf16raw*)dy, (const bf16raw*)x, mean, rstd, gamma, (bf16raw*)dx, work, dxsum,
+    hipLaunchKernelGGL(layernorm_bwd_pf_k<FROM_OUT>, grid, block, 0, st, (const bf16raw*)dy, (const bf16raw*)x, mean, rstd, gamma, (bf16raw*)dx, work, dxsum,
                        (long long)rows, (int)d);
   else if (nch == 1) LN_B(1); else if (nch == 2) LN_B(2); else LN_B(4);
 #undef LN_B
@@ -366,10 +380,23 @@ extern "C" int pero_layernorm_bwd(const void* dy, const void* x, const float* me
   PERO_REQUIRE(dy && x && mean && rstd && gamma && dx && dgamma && dbeta && work, "pero_layernorm_bwd: null pointer");
   PERO_REQUIRE(rows > 0 && d > 0 && d % 8 == 0 && d <= 2048, "pero_layernorm_bwd: need d %% 8 == 0 and d <= 2048 (d=%lld)", (long long)d);
   PERO_REQUIRE(aligned16(dy) && aligned16(x) && aligned16(dx) && aligned16(gamma), "pero_layernorm_bwd: 16-byte alignment");
-  if (dtype == PERO_F32) ln_dispatch_bwd<float>(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, dxsum, work, rows, d, (hipStream_t)stream);
-  else if (dtype == PERO_BF16) ln_dispatch_bwd<bf16raw>(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, dxsum, work, rows, d, (hipStream_t)stream);
+  if (dtype == PERO_F32) ln_dispatch_bwd<float, false>(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, dxsum, work, rows, d, (hipStream_t)stream);
+  else if (dtype == PERO_BF16) ln_dispatch_bwd<bf16raw, false>(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, dxsum, work, rows, d, (hipStream_t)stream);
   else PERO_REQUIRE(false, "pero_layernorm_bwd: bad dtype");
   PERO_CHECK_LAUNCH("pero_layernorm_bwd");
+  return PERO_OK;
+}
+
+extern "C" int pero_layernorm_bwd_out(const void* dy, const void* t, const float* rstd, const float* gamma, const float* beta,
+                                      void* dx, float* dgamma, float* dbeta, float* dxsum, float* work, int64_t rows, int64_t d,
+                                      int dtype, void* stream) {
+  PERO_REQUIRE(dy && t && rstd && gamma && beta && dx && dgamma && dbeta && work, "pero_layernorm_bwd_out: null pointer");
+  PERO_REQUIRE(rows > 0 && d > 0 && d % 8 == 0 && d <= 2048, "pero_layernorm_bwd_out: need d %% 8 == 0 and d <= 2048 (d=%lld)", (long long)d);
+  PERO_REQUIRE(aligned16(dy) && aligned16(t) && aligned16(dx) && aligned16(gamma) && aligned16(beta), "pero_layernorm_bwd_out: 16-byte alignment");
+  if (dtype == PERO_F32) ln_dispatch_bwd<float, true>(dy, t, beta, rstd, gamma, dx, dgamma, dbeta, dxsum, work, rows, d, (hipStream_t)stream);
+  else if (dtype == PERO_BF16) ln_dispatch_bwd<bf16raw, true>(dy, t, beta, rstd, gamma, dx, dgamma, dbeta, dxsum, work, rows, d, (hipStream_t)stream);
+  else PERO_REQUIRE(false, "pero_layernorm_bwd_out: bad dtype");
+  PERO_CHECK_LAUNCH("pero_layernorm_bwd_out");
   return PERO_OK;
 }
 

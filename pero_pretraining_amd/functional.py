@@ -198,14 +198,33 @@ FUSE_LN_FWD_MAX_K = 4096  # Linear + residual + LayerNorm as ONE launch (csrc/ge
                           # 2048-line step: never 147.7 ms, out-projection only 147.0, both 146.8.  0: never
 
 
-def linear_resid_ln_fwd(x, lin_w, lin_b, resid, norm, dtype):
-    """y = x @ W^T + b + resid ; t, mean, rstd = LayerNorm(y): fused where the shape and the reduction length allow, else the pair."""
+LN_BWD_FROM_OUT = True    # bf16 mode: the encoder layers' LayerNorms keep their OUTPUT t (the next Linear's input, saved anyway) and rstd for the backward,
+                          # not their input rows y ("memory-efficient" LayerNorm: xhat = (t - beta) / gamma, pero_layernorm_bwd_out).  The fused
+                          # Linear + residual + LayerNorm launch then does not store y at all: 24 x 537 MB per 2048-line step less written and kept.
+                          # f32 parity mode always keeps y (the reference's arithmetic: torch.nn.LayerNorm saves its input)
+
+
+def ln_from_out(dtype):
+    return LN_BWD_FROM_OUT and dtype == torch.bfloat16
+
+
+def linear_resid_ln_fwd(x, lin_w, lin_b, resid, norm, dtype, keep_y=True):
+    """y = x @ W^T + b + resid ; t, mean, rstd = LayerNorm(y): fused where the shape and the reduction length allow, else the pair.
+    keep_y=False: y is not needed afterwards (returned as None; the fused launch does not even store it)."""
     if (dtype == torch.bfloat16 and FUSE_LN_FWD_MAX_K and x.shape[1] <= FUSE_LN_FWD_MAX_K and lin_b is not None and
             ops.gemm_resid_layernorm_ok(x, lowp.weight(lin_w, dtype), resid)):
-        return ops.gemm_resid_layernorm(x, lowp.weight(lin_w, dtype), lin_b.detach(), resid, norm.weight.detach(), norm.bias.detach(), norm.eps)
+        return ops.gemm_resid_layernorm(x, lowp.weight(lin_w, dtype), lin_b.detach(), resid, norm.weight.detach(), norm.bias.detach(), norm.eps,
+                                        store_y=keep_y)
     y = linear_fwd(x, lin_w, lin_b, dtype, residual=resid)
     t, mean, rstd = ops.layernorm_fwd(y, norm.weight.detach(), norm.bias.detach(), norm.eps)
-    return y, t, mean, rstd
+    return (y if keep_y else None), t, mean, rstd
+
+
+def ln_bwd(dt, y, t, mean, rstd, norm, dxsum):
+    """LayerNorm backward of an encoder layer's norm: from the saved input rows y, or - when the forward did not keep them - from its output t."""
+    if y is None:
+        return ops.layernorm_bwd_out(dt, t, rstd, norm.weight.detach(), norm.bias.detach(), ensure_grad(norm.weight), ensure_grad(norm.bias), dxsum)
+    return ops.layernorm_bwd(dt, y, mean, rstd, norm.weight.detach(), ensure_grad(norm.weight), ensure_grad(norm.bias), dxsum)
 
 
 def layer_fwd(t, L, n, s, h, dtype, save):
@@ -215,30 +234,29 @@ def layer_fwd(t, L, n, s, h, dtype, save):
         a, p = ops.attention_fwd_fused(qkv, n, s, h)   # p = base-2 log-sum-exp rows (N*h, S)
     else:
         a, p = attention_fwd(qkv, n, s, h)             # p = probabilities (N*h, S, S)
-    y1, t1, mean1, rstd1 = linear_resid_ln_fwd(a, at.out_proj.weight, at.out_proj.bias, t, L.norm1, dtype)
+    keep_y = not (save and ln_from_out(dtype))
+    y1, t1, mean1, rstd1 = linear_resid_ln_fwd(a, at.out_proj.weight, at.out_proj.bias, t, L.norm1, dtype, keep_y=keep_y)
     bits = None
     if save and DX_ON_WT and relu_bits_ok(t1.shape[0], L.linear1.weight.shape[0], t1.shape[1], dtype) and \
             relu_bits_ok(t1.shape[0], L.linear1.weight.shape[0], L.linear2.weight.shape[0], dtype):
         bits = torch.empty((t1.shape[0], L.linear1.weight.shape[0] // 8), device=t1.device, dtype=torch.uint8)
     hdn = linear_fwd(t1, L.linear1.weight, L.linear1.bias, dtype, relu=True, relu_bits=bits)
-    y2, t2, mean2, rstd2 = linear_resid_ln_fwd(hdn, L.linear2.weight, L.linear2.bias, t1, L.norm2, dtype)
-    saved = (t, qkv, p, a, y1, mean1, rstd1, t1, hdn, y2, mean2, rstd2, bits) if save else None
+    y2, t2, mean2, rstd2 = linear_resid_ln_fwd(hdn, L.linear2.weight, L.linear2.bias, t1, L.norm2, dtype, keep_y=keep_y)
+    saved = (t, qkv, p, a, y1, mean1, rstd1, t1, hdn, y2, mean2, rstd2, bits, t2) if save else None
     return t2, saved
 
 
 def layer_bwd(dt2, L, saved, n, s, h, dtype, side=None):
-    t, qkv, p, a, y1, mean1, rstd1, t1, hdn, y2, mean2, rstd2, bits = saved
+    t, qkv, p, a, y1, mean1, rstd1, t1, hdn, y2, mean2, rstd2, bits, t2 = saved
     at = L.self_attn
     # LN2 (its dx column sums are linear2's bias gradient)
-    dy2 = ops.layernorm_bwd(dt2, y2, mean2, rstd2, L.norm2.weight.detach(), ensure_grad(L.norm2.weight),
-                            ensure_grad(L.norm2.bias), ensure_grad(L.linear2.bias))
+    dy2 = ln_bwd(dt2, y2, t2, mean2, rstd2, L.norm2, ensure_grad(L.linear2.bias))
     # linear1's bias gradient = column sums of dpre1: accumulated by the epilogue of the product that writes dpre1
     fuse_b1 = FUSE_BIAS_GRAD and FUSE_B1_COLSUM and dtype == torch.bfloat16 and L.linear1.bias is not None and L.linear1.bias.requires_grad
     dpre1 = linear_bwd(dy2, hdn, L.linear2.weight, L.linear2.bias, dtype, gate=hdn, gate_bits=bits, bias_grad_done=True, side=side,
                        dx_colsum_into=ensure_grad(L.linear1.bias) if fuse_b1 else None)
     dt1 = linear_bwd(dpre1, t1, L.linear1.weight, L.linear1.bias, dtype, residual=dy2, side=side, bias_grad_done=fuse_b1)
-    dy1 = ops.layernorm_bwd(dt1, y1, mean1, rstd1, L.norm1.weight.detach(), ensure_grad(L.norm1.weight),
-                            ensure_grad(L.norm1.bias), ensure_grad(at.out_proj.bias))
+    dy1 = ln_bwd(dt1, y1, t1, mean1, rstd1, L.norm1, ensure_grad(at.out_proj.bias))
     fused_attn = p.dim() == 2
     dvec = None
     if fused_attn and FUSE_ROWDOT and a.shape[1] % 128 == 0:

@@ -139,11 +139,12 @@ def gemm_resid_layernorm_ok(a, w, residual):
             a.stride(1) == 1 and w.stride(1) == 1 and residual.stride(1) == 1 and a.stride(0) % 8 == 0 and w.stride(0) % 8 == 0 and residual.stride(0) % 8 == 0)
 
 
-def gemm_resid_layernorm(a, w, bias, residual, gamma, beta, eps):
-    """y = a @ w^T + bias + residual (bf16, stored), t = LayerNorm(y) * gamma + beta, mean, rstd - ONE launch (pero_gemm_resid_layernorm)."""
+def gemm_resid_layernorm(a, w, bias, residual, gamma, beta, eps, store_y=True):
+    """y = a @ w^T + bias + residual (bf16, stored unless store_y=False: then None), t = LayerNorm(y) * gamma + beta, mean, rstd - ONE launch
+    (pero_gemm_resid_layernorm)."""
     _req_cuda(a)
     M, K = a.shape
-    y = torch.empty((M, 512), device=a.device, dtype=torch.bfloat16)
+    y = torch.empty((M, 512), device=a.device, dtype=torch.bfloat16) if store_y else None
     t = torch.empty((M, 512), device=a.device, dtype=torch.bfloat16)
     mean = torch.empty(M, device=a.device, dtype=torch.float32)
     rstd = torch.empty(M, device=a.device, dtype=torch.float32)
@@ -151,7 +152,7 @@ def gemm_resid_layernorm(a, w, bias, residual, gamma, beta, eps):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     call("pero_gemm_resid_layernorm", ptr(a), ptr(w), ptr(bias), ptr(residual), ptr(gamma), ptr(beta), ptr(y), ptr(t), ptr(mean), ptr(rstd),
-         M, 512, K, a.stride(0), w.stride(0), y.stride(0), residual.stride(0), t.stride(0), float(eps), stream())
+         M, 512, K, a.stride(0), w.stride(0), y.stride(0) if y is not None else 0, residual.stride(0), t.stride(0), float(eps), stream())
     if gemm_timeline is not None:   # counted with the tile GEMMs of bench.py's roofline: the product's flops over the WHOLE launch (LayerNorm included)
         e1.record()
         gemm_timeline.append((e0, e1, 2.0 * M * 512 * K, "gemm_bf16_tile:NN"))
@@ -164,6 +165,16 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, dxsum=None):
     work = torch.empty(3 * _lib.LN_BWD_BLOCKS * d, device=x.device, dtype=torch.float32)
     call("pero_layernorm_bwd", ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(dx), ptr(dgamma), ptr(dbeta),
          ptr(dxsum), ptr(work), rows, d, dt(x), stream())
+    return dx
+
+
+def layernorm_bwd_out(dy, t, rstd, gamma, beta, dgamma, dbeta, dxsum=None):
+    """LayerNorm backward from the layer's OUTPUT t (pero_layernorm_bwd_out): the forward kept t and rstd only."""
+    rows, d = t.shape
+    dx = torch.empty_like(t)
+    work = torch.empty(3 * _lib.LN_BWD_BLOCKS * d, device=t.device, dtype=torch.float32)
+    call("pero_layernorm_bwd_out", ptr(dy), ptr(t), ptr(rstd), ptr(gamma), ptr(beta), ptr(dx), ptr(dgamma), ptr(dbeta),
+         ptr(dxsum), ptr(work), rows, d, dt(t), stream())
     return dx
 
 

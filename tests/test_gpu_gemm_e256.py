@@ -252,3 +252,6 @@ def test_fused_linear_residual_layernorm(e256, M, K):
         for _ in range(3):
             again = ops.gemm_resid_layernorm(x, w, b, res, gamma, beta, 1e-5)
             assert all(torch.equal(a, c) for a, c in zip(again, (y, t, mean, rstd)))
+        # the launch that does not store y (the backward then reads t: pero_layernorm_bwd_out): the same t, mean, rstd, bit for bit
+        yn, tn, mn, rn = ops.gemm_resid_layernorm(x, w, b, res, gamma, beta, 1e-5, store_y=False)
+        assert yn is None and torch.equal(tn, t) and torch.equal(mn, mean) and torch.equal(rn, rstd)

@@ -338,6 +338,50 @@ def test_layernorm_fwd_bwd(ops, dtype, rows, d):
     assert rel_err(dxs, xr.grad.sum(0)) < 1e-4  # column sums are taken in f32 before dx is rounded
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,d", [(37, 64), (300, 512), (4096 + 6, 512), (50, 1024)])
+def test_layernorm_bwd_from_output(ops, dtype, rows, d):
+    """pero_layernorm_bwd_out: the backward from the layer's OUTPUT t = xhat * gamma + beta and rstd (the input rows are not kept).  f32: the
+    gradients of the autograd oracle to rounding; bf16: t carries one more 2^-9 rounding than the input-row form, so dx is held to a few
+    bf16 steps and the column sums to 1e-2 of their range.  A column with gamma == 0 has lost its xhat (t = beta there): its gamma gradient
+    and its own dx column (the -xhat * c2 term) are those of xhat = 0, every other column is unaffected, nothing is NaN - the documented limit
+    of the form (pero_hip.h)."""
+    g = torch.Generator().manual_seed(7 * rows + d)
+    x = (torch.randn(rows, d, generator=g) * 2 + 0.3).to(dtype)
+    gamma = torch.rand(d, generator=g) + 0.5
+    gamma[1::7] *= -1.0
+    beta = torch.randn(d, generator=g) * 0.3
+    xr, gr, br = x.float().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    y_ref = O.layer_norm(xr, gr, br)
+    dy = torch.randn(rows, d, generator=g).to(dtype)
+    y_ref.backward(dy.float())
+    t, mean, rstd = ops.layernorm_fwd(dev(x), dev(gamma), dev(beta), 1e-5)
+    dg, db, dxs = (torch.zeros(d, device="cuda") for _ in range(3))
+    dx = ops.layernorm_bwd_out(dev(dy), t, rstd, dev(gamma), dev(beta), dg, db, dxs)
+    f32 = dtype == torch.float32
+    assert rel_err(dx, xr.grad) < (1e-4 if f32 else 2 ** -5)
+    assert rel_err(dg, gr.grad) < (1e-4 if f32 else 1e-2)
+    assert rel_err(db, br.grad) < 1e-4
+    assert rel_err(dxs, xr.grad.sum(0)) < (1e-3 if f32 else 2e-2)
+    # ... and next to the input-row form of the same library
+    dg2, db2, dxs2 = (torch.zeros(d, device="cuda") for _ in range(3))
+    dx2 = ops.layernorm_bwd(dev(dy), dev(x), mean, rstd, dev(gamma), dg2, db2, dxs2)
+    assert rel_err(dx, dx2.float().cpu()) < (1e-4 if f32 else 2 ** -5)
+    assert torch.equal(db, db2)
+    if f32:
+        gz = gamma.clone()
+        gz[3] = 0.0
+        t, mean, rstd = ops.layernorm_fwd(dev(x), dev(gz), dev(beta), 1e-5)
+        dg, db, dxs = (torch.zeros(d, device="cuda") for _ in range(3))
+        dx = ops.layernorm_bwd_out(dev(dy), t, rstd, dev(gz), dev(beta), dg, db, dxs)
+        dg2, db2, dxs2 = (torch.zeros(d, device="cuda") for _ in range(3))
+        dx2 = ops.layernorm_bwd(dev(dy), dev(x), mean, rstd, dev(gz), dg2, db2, dxs2)
+        keep = torch.ones(d, dtype=torch.bool)
+        keep[3] = False
+        assert bool(torch.isfinite(dx).all()) and rel_err(dx[:, keep.cuda()], dx2[:, keep.cuda()].cpu()) < 1e-4
+        assert rel_err(dg[keep.cuda()], dg2[keep.cuda()].cpu()) < 1e-4 and float(dg[3]) == 0.0
+
+
 @pytest.mark.parametrize("rows,d", [(4096 + 13, 512), (8192, 256), (5000, 504)])
 def test_layernorm_fwd_four_rows_per_wave_equals_one_row_per_wave(ops, rows, d):
     """bf16, d <= 512, >= 4096 rows, no positional table: the four-rows-per-wave kernel - the rows, means and rstds it writes are those
