@@ -122,6 +122,16 @@ int pero_gemm_resid_layernorm(const void* A, const void* W, const float* bias, c
                               void* Y, void* T, float* mean, float* rstd, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw,
                               int64_t ldy, int64_t ldr, int64_t ldt, float eps, void* stream);
 
+/* Input gradient of a Linear + residual gradient + LayerNorm BACKWARD of the norm in front of that Linear, in ONE launch (round 4; bf16, N = 512,
+ * M % 128 == 0, K % 64 == 0, K >= 192): dt = A Wt^T + R with the rows complete in a workgroup (Wt = the transposed bf16 weight copy, N x K), then
+ * pero_layernorm_bwd_out's arithmetic on the rounded dt: DX = rstd (dt gamma - mean(dt gamma) - xhat mean(dt gamma xhat)), xhat = (T - beta) / gamma;
+ * dgamma / dbeta / dxsum (dxsum may be null) are ACCUMULATED (+=) from per-workgroup partial column sums.  dt itself never reaches memory: replaces
+ * pero_gemm (residual epilogue) + pero_layernorm_bwd_out for the two input-gradient products of TransformerEncoderLayer that feed a norm's backward
+ * (linear1 -> norm1, in_proj -> the previous layer's norm2; models/transformers.py:36-43).  work: f32, 3 * PERO_LN_BWD_BLOCKS * 512 elements. */
+int pero_gemm_resid_layernorm_bwd(const void* A, const void* Wt, const void* R, const void* T, const float* rstd, const float* gamma,
+                                  const float* beta, void* DX, float* dgamma, float* dbeta, float* dxsum, float* work, int64_t M, int64_t N,
+                                  int64_t K, int64_t lda, int64_t ldw, int64_t ldr, int64_t ldt, int64_t lddx, void* stream);
+
 /* ---- LayerNorm (+ positional encoding) --------------------------------------------------------------
  * y = (x - mean) * rstd * gamma + beta (+ pe[offsets[row / S] + row % S]) ; rows x d.
  * Replaces torch.nn.LayerNorm (models/transformers.py:28,83-84 and the norm1/norm2 of

@@ -429,6 +429,24 @@ extern "C" int pero_gemm_resid_layernorm(const void* A, const void* W, const flo
   PERO_CHECK_LAUNCH("pero_gemm_resid_layernorm");
   return PERO_OK;
 }
+extern "C" int pero_gemm_resid_layernorm_bwd(const void* A, const void* Wt, const void* R, const void* T, const float* rstd, const float* gamma,
+                                             const float* beta, void* DX, float* dgamma, float* dbeta, float* dxsum, float* work, int64_t M, int64_t N,
+                                             int64_t K, int64_t lda, int64_t ldw, int64_t ldr, int64_t ldt, int64_t lddx, void* stream) {
+  PERO_REQUIRE(A && Wt && R && T && rstd && gamma && beta && DX && dgamma && dbeta && work, "pero_gemm_resid_layernorm_bwd: null pointer");
+  PERO_REQUIRE(N == 512 && M > 0 && M % 128 == 0 && K % 64 == 0 && K >= 192 && lda % 8 == 0 && ldw % 8 == 0 && ldr % 8 == 0 && ldt % 8 == 0 &&
+               lddx % 8 == 0 && aligned16(A) && aligned16(Wt) && aligned16(R) && aligned16(T) && aligned16(DX) && aligned16(gamma) && aligned16(beta),
+               "pero_gemm_resid_layernorm_bwd: bf16, N = 512, M %% 128 == 0, K %% 64 == 0, K >= 192, 16-byte aligned rows");
+  GemmP p;
+  p.A = A; p.B = Wt; p.C = DX; p.bias = nullptr; p.resid = R; p.gate = nullptr;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldw; p.ldc = lddx; p.ldr = ldr; p.ldg = 0;
+  p.sAo = p.sAi = p.sBo = p.sBi = p.sCo = p.sCi = 0;
+  p.binner = 1; p.alpha = 1.0f; p.flags = 0; p.kchunk = K;
+  int grid = 0;
+  PERO_REQUIRE(pero_launch_gemm_n512_lnb(p, T, ldt, rstd, gamma, beta, work, &grid, (hipStream_t)stream), "pero_gemm_resid_layernorm_bwd: shape not taken");
+  pero_ln_bwd_reduce_launch(work, dgamma, dbeta, dxsum, grid, 512, (hipStream_t)stream);
+  PERO_CHECK_LAUNCH("pero_gemm_resid_layernorm_bwd");
+  return PERO_OK;
+}
 extern "C" int64_t pero_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K, int64_t batch, int flags, int k_split, int in_dtype,
                                              int out_dtype) {
   if (!(flags & PERO_GEMM_ATOMIC) || batch != 1 || in_dtype != PERO_BF16 || out_dtype != PERO_F32 || (flags & PERO_GEMM_FORCE_GENERIC) || M <= 0 ||

@@ -39,3 +39,7 @@ long long pero_gemm_e256_splitk_ws_bytes(long long M, long long N, long long K, 
 bool pero_launch_gemm_n512(const GemmP& p, long long batch, bool ta, bool tb, bool out_f32, hipStream_t st);
 bool pero_launch_gemm_n512_ln(const GemmP& p, void* t, long long ldt, float* mean, float* rstd, const float* gamma, const float* beta, float eps,
                               hipStream_t st);
+bool pero_launch_gemm_n512_lnb(const GemmP& p, const void* t, long long ldt, const float* rstd, const float* gamma, const float* beta, float* work,
+                               int* grid_out, hipStream_t st);
+// rowops.hip: dgamma / dbeta / dxsum (each may be null) += the sum of the `nblocks` partial rows of work [3][nblocks][d]
+void pero_ln_bwd_reduce_launch(const float* work, float* dgamma, float* dbeta, float* dxsum, int nblocks, int d, hipStream_t st);

@@ -61,8 +61,13 @@
 #define EP_SPLITK 7      // f32 C += partial product of ONE k-slice (atomics): one work item (tile, k-slice) per workgroup, not persistent
 #define EP_RESID_LN 8    // (gemm_bf16_n512 only) bias, + residual -> y stored; LayerNorm of the stored rows -> t, mean, rstd (LnP)
 #define EP_RESID_LN_T 9  // the same without the stores of y (the backward reads t: pero_layernorm_bwd_out): the epilogue's counted waits differ
+#define EP_RESID_LNB 10  // (gemm_bf16_n512 only) input gradient of a Linear + residual gradient = dt, rows complete -> LayerNorm BACKWARD of the upstream norm
+                         // in the epilogue (from its output t and rstd, pero_layernorm_bwd_out's arithmetic): dx stored, dt never; column sums -> LnP.work
 // second argument of gemm_bf16_n512: what the LayerNorm epilogue writes and reads beside GemmP
-struct LnP { void* t; long long ldt; float* mean; float* rstd; const float* gamma; const float* beta; float eps; };
+struct LnP { void* t; long long ldt; float* mean; float* rstd; const float* gamma; const float* beta; float eps; float* work; };
+typedef float ef2v __attribute__((ext_vector_type(2)));
+#define E_BLOAD4(dst_, voff_, rs_, soff_, imm_) \
+  asm volatile("s_nop 4\n\tbuffer_load_dword %0, %1, %2, %3 offen offset:%4" : "=v"(dst_) : "v"(voff_), "s"(rs_), "s"(soff_), "i"(imm_) : "memory")
 
 typedef int ei4v __attribute__((ext_vector_type(4)));
 typedef short es2v __attribute__((ext_vector_type(2)));
@@ -852,16 +857,21 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p, int ks) {
 template <int EPI, bool BIAS>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_n512(GemmP p, LnP q) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  static_assert(EPI == EP_PLAIN || EPI == EP_RESID || EPI == EP_RESID_LN || EPI == EP_RESID_LN_T, "the row-complete tile has the plain, the residual and the residual + LayerNorm epilogue");
+  static_assert(EPI == EP_PLAIN || EPI == EP_RESID || EPI == EP_RESID_LN || EPI == EP_RESID_LN_T || EPI == EP_RESID_LNB,
+                "the row-complete tile has the plain, the residual, the residual + LayerNorm and the residual + LayerNorm-backward epilogue");
+  static_assert(EPI != EP_RESID_LNB || !BIAS, "an input-gradient product has no bias");
   constexpr bool LN = EPI == EP_RESID_LN || EPI == EP_RESID_LN_T;
+  constexpr bool LNB = EPI == EP_RESID_LNB;
   constexpr bool STORE_Y = EPI != EP_RESID_LN_T;
-  constexpr bool RES = EPI == EP_RESID || LN;
+  constexpr bool RES = EPI == EP_RESID || LN || LNB;
   constexpr int LB = BIAS ? 4 : 0;                        // bias side loads (16 B per lane each)
   constexpr int L0 = LB + (RES ? 8 : 0);                  // side loads issued in phase 4 of the last K-tile: bias + residual rows 0-63
   constexpr int L1 = RES ? 8 : 0;                         // residual rows 64-127, issued halfway through rows 0-63
   constexpr int SH = STORE_Y ? 8 : 0;                     // stores per half of the epilogue
   constexpr int LNX = LN ? 8 + 2 + 16 : 0;                // LayerNorm: gamma / beta loads, mean / rstd stores, the 16 stores of t
-  constexpr int EPO = L1 + 2 * SH + LNX;                  // vector-memory operations of an epilogue behind its phase-4 side loads
+  // vector-memory operations of an epilogue behind its phase-4 side loads.  LayerNorm backward: residual rows 64-127 (8), t rows 0-63 (8), gamma, beta,
+  // rstd, t rows 64-127 (4 + 4 + 8 + 8), the rows of t again for pass 2 (16), the 16 stores of dx
+  constexpr int EPO = LNB ? (8 + 8 + 24 + 16 + 16) : (L1 + 2 * SH + LNX);
   constexpr int cap63 = 63;                               // s_waitcnt vmcnt takes six bits: a larger count only asks for more than needed
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -960,7 +970,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_n512(GemmP p, LnP q) {
   unsigned char* const xstg = smem + N_XSTG + wave * 2048;
   const ei4v brs = ersrc(BIAS ? (const void*)(p.bias + 256 * wr) : (const void*)p.B, 256 * 4);
   eu4v side0[8], side1[8];   // residual rows 0-63 / 64-127 (EP_RESID)
+  eu4v tside0[8], tside1[8]; // EP_RESID_LNB: the rows of t (the LayerNorm's output), same layout
   eu4v biasr[4];             // the lane's 16 bias values as the accumulators hold them: [hb * 2 + j]
+  float run_g = 0.f, run_b = 0.f, run_x = 0.f;   // EP_RESID_LNB: the wave's column sums (dgamma, dbeta, sum of dx), one column per lane, over the workgroup's tiles
+  (void)tside0; (void)tside1; (void)run_g; (void)run_b; (void)run_x;
 
   for (;;) {
 #pragma unroll
@@ -973,6 +986,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_n512(GemmP p, LnP q) {
           for (int j = 0; j < 2; j++) acc[ha][hb][i][j] = (f4v){0.f, 0.f, 0.f, 0.f};
     const int spitch = (int)(p.ldr * 2);
     const ei4v srs = ersrc(RES ? (const void*)((const bf16raw*)p.resid + tm0 * p.ldr) : (const void*)p.B, (unsigned)(128 * (RES ? spitch : 2)));
+    const int tpitch_l = (int)(q.ldt * 2);
+    const ei4v trs_l = ersrc(LNB ? (const void*)((const bf16raw*)q.t + tm0 * q.ldt) : (const void*)p.B, (unsigned)(128 * (LNB ? tpitch_l : 2)));
+    (void)tpitch_l;
 
     auto ktile = [&](auto last_c, auto t0_c, const int t) __attribute__((always_inline)) {
       constexpr bool last = decltype(last_c)::value, t0 = decltype(t0_c)::value;
@@ -1047,6 +1063,235 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_n512(GemmP p, LnP q) {
     // ---- epilogue, straight from the accumulators
     first = false;
     if (wr == 0) { N_BAR(); }   // undo the stagger: both groups run their epilogues side by side
+    if constexpr (LNB) {
+      // ---- Linear input gradient + residual gradient = dt (rows complete in this workgroup) -> LayerNorm backward of the upstream norm, from its
+      // output t and rstd (layernorm_bwd_pf_k<true>'s arithmetic on the ROUNDED dt, as the unfused pair has it): xhat = (t - beta) / gamma,
+      // g = dt gamma, c1 = mean(g), c2 = mean(g xhat), dx = rstd (g - c1 - xhat c2); dgamma += dt xhat, dbeta += dt, dxsum += dx per column.
+      //   pass 1a  accumulators + residual rows -> dt through the lane transpose, rounded and PACKED (the accumulators die here)
+      //   pass 1b  the two row sums of the lane's 16 columns, all eight rows;  partials of the eight waves -> the A slot this tile's last K-tile has
+      //            left free (the next tile's third K-tile refills it), ONE barrier
+      //   pass 2   four chunks (32-column block hb, row half ha) of four rows: the rows of t come a SECOND time (from the L2 now: kept in registers
+      //            beside the packed dt, the constants and the column sums they spilled 160 registers), per row the totals from the exchange area,
+      //            dx stored; per block the column sums, reduced over the wave's 16 row indices at once.
+      // Vector-memory order (per lane): [phase 4 of the last K-tile: residual rows 0-63 x8] | residual rows 64-127 x8 (halfway through pass 1a of rows 0-63) | t rows 0-63 x8 | gamma x4,
+      // beta x4, rstd x8, t rows 64-127 x8 | t chunks 0, 1 (4 + 4) | 4 stores | t chunk 2 | 4 stores | t chunk 3 | 4 + 4 stores.
+      int lane_e = lane;
+      asm volatile("" : "+v"(lane_e));
+      const int li_e = lane_e & 15, lq_e = lane_e >> 4;
+      const int er = lane_e >> 2, ep = lane_e & 3;
+      const unsigned cvo = (unsigned)((er * p.ldc + 256 * wr + 64 * wc + 8 * ep) * 2);
+      const unsigned gvo = (unsigned)((er * p.ldr + 256 * wr + 64 * wc + 8 * ep) * 2);
+      const unsigned tvo = (unsigned)((er * q.ldt + 256 * wr + 64 * wc + 8 * ep) * 2);
+      const int xsw = (li_e ^ ((li_e >> 1) & 1)) & 7, xsr = (er ^ ((er >> 1) & 1)) & 7;
+      const unsigned xw32 = (unsigned)(li_e * 128), xr32 = (unsigned)(er * 128);
+      const ei4v crs = ersrc((bf16raw*)p.C + tm0 * p.ldc, (unsigned)(128 * p.ldc * 2));
+      const int cpitch = (int)(p.ldc * 2);
+      float* const X = (float*)(aring + mod3(ga + 2) * E_HALF);   // exchange area: [8 waves][2 sums][128 rows] floats, 260 per wave (4 of padding: the 32 addresses of a half wave's ds_read_b32 fall on 32 banks)
+      auto quad = [&](float v) -> float {
+        v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xf, 0xf, false));
+        v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xf, 0xf, false));
+        return v;
+      };
+      auto lo2 = [](unsigned w) -> ef2v { return (ef2v){__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)}; };
+      eu4v dtp[2][4][2];
+      auto pass1a = [&](auto ha_c) __attribute__((always_inline)) {
+        constexpr int ha = decltype(ha_c)::value;
+        auto& side1_ = side1;   // (hipcc does not capture a variable that a generic lambda names only as an asm operand)
+        const unsigned gvo_ = gvo;
+        const ei4v srs_ = srs;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          if (ha == 0 && i == 2) {
+            // residual rows 64-127 go out HALFWAY through rows 0-63: half of that half's accumulators and residual registers are free by now
+            // (requested at the epilogue's start they sat beside all 128 accumulators: 16 spilled registers)
+#pragma unroll
+            for (int i2 = 0; i2 < 4; i2++) {
+              const int so = (64 + 16 * i2) * spitch;
+              E_BLOAD16(side1_[2 * i2], gvo_, srs_, so, 0);
+              E_BLOAD16(side1_[2 * i2 + 1], gvo_, srs_, so, 64);
+            }
+          }
+#pragma unroll
+          for (int hb = 0; hb < 2; hb++) {
+            const f4v x = acc[ha][hb][i][0], y = acc[ha][hb][i][1];
+            *(f4v*)(xstg + xw32 + ((lq_e ^ xsw) << 4)) = x;
+            *(f4v*)(xstg + xw32 + (((4 + lq_e) ^ xsw) << 4)) = y;
+            const f4v r0 = *(const f4v*)(xstg + xr32 + (((2 * ep) ^ xsr) << 4));
+            const f4v r1 = *(const f4v*)(xstg + xr32 + (((2 * ep + 1) ^ xsr) << 4));
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; e++) { v[e] = r0[e]; v[4 + e] = r1[e]; }
+            const eu4v r4 = ha ? side1[2 * i + hb] : side0[2 * i + hb];
+#pragma unroll
+            for (int e = 0; e < 4; e++) { v[2 * e] += __uint_as_float(r4[e] << 16); v[2 * e + 1] += __uint_as_float(r4[e] & 0xffff0000u); }
+            dtp[ha][i][hb] = (eu4v){pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+            // (the packed rows are made opaque HERE: left alone the compiler sinks the adds and conversions down to the rows' first use in pass 1b and
+            //  parks the f32 rows of all eight units - 64 registers - in scratch meanwhile)
+            asm volatile("" : "+v"(dtp[ha][i][hb]));
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+      E_WAIT8(4, side0);   // residual rows 0-63 (phase 4 of the last K-tile): newer are B00 / B10 (4)
+      pass1a(std::integral_constant<int, 0>{});
+#pragma unroll
+      for (int i = 0; i < 4; i++) {   // t rows 0-63
+        const int so = 16 * i * tpitch_l;
+        E_BLOAD16(tside0[2 * i], tvo, trs_l, so, 0);
+        E_BLOAD16(tside0[2 * i + 1], tvo, trs_l, so, 64);
+      }
+      E_WAIT8(8, side1);    // newer: the 8 loads just issued
+      pass1a(std::integral_constant<int, 1>{});
+      // gamma / beta of the lane's 16 columns ([2 hb + half]), rstd of its eight rows, t rows 64-127
+      const ei4v grs = ersrc(q.gamma + 256 * wr + 64 * wc, 64 * 4), ers = ersrc(q.beta + 256 * wr + 64 * wc, 64 * 4);
+      const ei4v rrs = ersrc(q.rstd + tm0, 128 * 4);
+      const unsigned gvoff = (unsigned)(8 * ep * 4), rvo = (unsigned)(er * 4);
+      eu4v cg[4], cb[4];
+      unsigned rsr[8];
+      E_BLOAD16(cg[0], gvoff, grs, 0, 0); E_BLOAD16(cg[1], gvoff, grs, 0, 16); E_BLOAD16(cg[2], gvoff, grs, 0, 128); E_BLOAD16(cg[3], gvoff, grs, 0, 144);
+      E_BLOAD16(cb[0], gvoff, ers, 0, 0); E_BLOAD16(cb[1], gvoff, ers, 0, 16); E_BLOAD16(cb[2], gvoff, ers, 0, 128); E_BLOAD16(cb[3], gvoff, ers, 0, 144);
+      E_BLOAD4(rsr[0], rvo, rrs, 0, 0); E_BLOAD4(rsr[1], rvo, rrs, 0, 64); E_BLOAD4(rsr[2], rvo, rrs, 0, 128); E_BLOAD4(rsr[3], rvo, rrs, 0, 192);
+      E_BLOAD4(rsr[4], rvo, rrs, 256, 0); E_BLOAD4(rsr[5], rvo, rrs, 256, 64); E_BLOAD4(rsr[6], rvo, rrs, 256, 128); E_BLOAD4(rsr[7], rvo, rrs, 256, 192);
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int so = (64 + 16 * i) * tpitch_l;
+        E_BLOAD16(tside1[2 * i], tvo, trs_l, so, 0);
+        E_BLOAD16(tside1[2 * i + 1], tvo, trs_l, so, 64);
+      }
+      // t rows 0-63 and the constants: newer are the 8 loads of t rows 64-127
+      E_WAIT8(8, tside0);
+      E_WAIT4(8, cg);
+      E_WAIT4(8, cb);
+      asm volatile("s_waitcnt vmcnt(8)" : "+v"(rsr[0]), "+v"(rsr[1]), "+v"(rsr[2]), "+v"(rsr[3]), "+v"(rsr[4]), "+v"(rsr[5]), "+v"(rsr[6]), "+v"(rsr[7]) :: "memory");
+      // pair e of block hb <-> columns 32 hb + 8 ep + 2 e, + 1
+      auto Gp = [&](int hb, int e) -> ef2v { return (ef2v){__uint_as_float(cg[2 * hb + (e >> 1)][2 * (e & 1)]), __uint_as_float(cg[2 * hb + (e >> 1)][2 * (e & 1) + 1])}; };
+      auto Bp = [&](int hb, int e) -> ef2v { return (ef2v){__uint_as_float(cb[2 * hb + (e >> 1)][2 * (e & 1)]), __uint_as_float(cb[2 * hb + (e >> 1)][2 * (e & 1) + 1])}; };
+      // ---- pass 1b: s1 = sum dt gamma, s2 = sum dt (t - beta) (= dt gamma xhat) over the lane's 16 columns of each of its eight rows
+#pragma unroll
+      for (int ha = 0; ha < 2; ha++) {
+        if (ha == 1) E_WAIT8(0, tside1);   // (nothing newer; the older LDS-DMA of the next tile's first K-tiles has had the whole epilogue so far)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          ef2v a1 = {0.f, 0.f}, a2 = {0.f, 0.f};
+#pragma unroll
+          for (int hb = 0; hb < 2; hb++) {
+            const eu4v tw = ha ? tside1[2 * i + hb] : tside0[2 * i + hb];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+              const ef2v d = lo2(dtp[ha][i][hb][e]);
+              const ef2v u = lo2(tw[e]) - Bp(hb, e);
+              a1 = __builtin_elementwise_fma(d, Gp(hb, e), a1);
+              a2 = __builtin_elementwise_fma(d, u, a2);
+            }
+          }
+          const float q1 = quad(a1[0] + a1[1]), q2 = quad(a2[0] + a2[1]);
+          if (ep == 0) {
+            X[wave * 260 + 64 * ha + 16 * i + er] = q1;
+            X[wave * 260 + 128 + 64 * ha + 16 * i + er] = q2;
+          }
+        }
+      }
+      // ---- pass 2.  The rows of t again, chunk by chunk (c = 2 hb + ha: rows 64 ha + 16 i + er, the 16-byte piece of block hb), one chunk ahead
+      eu4v tc[2][4];
+      auto tload = [&](auto c_c) __attribute__((always_inline)) {
+        constexpr int c = decltype(c_c)::value, hb = c >> 1, ha = c & 1;
+        auto& tc_ = tc;   // (hipcc does not capture a variable that a generic lambda names only as an asm operand)
+        const unsigned tvo_ = tvo;
+        const ei4v trs_ = trs_l;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const int so = (64 * ha + 16 * i) * tpitch_l;
+          if (hb) E_BLOAD16(tc_[c & 1][i], tvo_, trs_, so, 64); else E_BLOAD16(tc_[c & 1][i], tvo_, trs_, so, 0);
+        }
+      };
+      tload(std::integral_constant<int, 0>{});
+      tload(std::integral_constant<int, 1>{});
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      N_BAR();
+      auto colred8 = [&](const ef2v (&A)[4]) -> float {
+        // 8 values per lane (columns 8 ep + j) summed over the wave's 16 row indices (lane bits 2-5): a halving butterfly over lanes 32, 16 and 8
+        // apart (each step a lane keeps half of its values and adds the partner's copy of them), then lane ^ 4; lane (er, ep) ends with the
+        // total of column 8 ep + (er >> 1)
+        float w4[4], w2[2];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(A[j >> 1][j & 1]), __float_as_uint(A[2 + (j >> 1)][j & 1]), false, false);
+          w4[j] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);      // er & 8 == 0: values j of both; else values j + 4 of both
+        }
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(w4[j]), __float_as_uint(w4[j + 2]), false, false);
+          w2[j] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);      // er & 4 == 0: w4[j] of both; else w4[j + 2] of both
+        }
+        const float s0 = w2[0] + __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(w2[0]), 0x128, 0xf, 0xf, false));   // row_ror:8 = lane ^ 8
+        const float s1 = w2[1] + __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(w2[1]), 0x128, 0xf, 0xf, false));
+        const float w1 = (er & 2) ? s1 : s0;
+        int r = __builtin_amdgcn_update_dpp(0, __float_as_int(w1), 0x104, 0xf, 0x5, false);    // lane ^ 4 (see gemm_bf16_e256's column sums)
+        r = __builtin_amdgcn_update_dpp(r, __float_as_int(w1), 0x114, 0xf, 0xa, false);
+        return w1 + __int_as_float(r);
+      };
+      float tot_g[2], tot_b[2], tot_x[2];
+      ef2v G[4], Bt[4], IG[4], AG[4], AB[4], AX[4];
+      auto chunk = [&](auto c_c) __attribute__((always_inline)) {
+        constexpr int c = decltype(c_c)::value, hb = c >> 1, ha = c & 1;
+        const unsigned cvo_ = cvo;
+        const ei4v crs_ = crs;
+        if constexpr (ha == 0) {
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            G[e] = Gp(hb, e); Bt[e] = Bp(hb, e);
+            IG[e][0] = G[e][0] != 0.f ? 1.0f / G[e][0] : 0.f;
+            IG[e][1] = G[e][1] != 0.f ? 1.0f / G[e][1] : 0.f;
+            AG[e] = (ef2v){0.f, 0.f}; AB[e] = (ef2v){0.f, 0.f}; AX[e] = (ef2v){0.f, 0.f};
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const int r = 64 * ha + 16 * i + er;
+          const float c1 = quad(X[(2 * ep) * 260 + r] + X[(2 * ep + 1) * 260 + r]) * (1.0f / 512.f);
+          const float c2 = quad(X[(2 * ep) * 260 + 128 + r] + X[(2 * ep + 1) * 260 + 128 + r]) * (1.0f / 512.f);
+          const float rs = __uint_as_float(rsr[4 * ha + i]);
+          const ef2v c1v = {-c1, -c1}, c2v = {-c2, -c2}, rsv = {rs, rs};
+          const int so = (64 * ha + 16 * i) * cpitch;
+          const eu4v tw = tc[c & 1][i];
+          eu4v od;
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            const ef2v d = lo2(dtp[ha][i][hb][e]);
+            const ef2v xh = (lo2(tw[e]) - Bt[e]) * IG[e];
+            ef2v o = __builtin_elementwise_fma(d, G[e], c1v);
+            o = __builtin_elementwise_fma(xh, c2v, o) * rsv;
+            AX[e] += o;
+            AG[e] = __builtin_elementwise_fma(d, xh, AG[e]);
+            AB[e] += d;
+            od[e] = pack2bf(o[0], o[1]);
+          }
+          if (hb) E_BSTORE16(od, cvo_, crs_, so, 64); else E_BSTORE16(od, cvo_, crs_, so, 0);
+        }
+        if constexpr (ha == 1) {
+          tot_g[hb] = colred8(AG);
+          tot_b[hb] = colred8(AB);
+          tot_x[hb] = colred8(AX);
+        }
+      };
+      E_WAIT4(4, tc[0]);                                   // chunk 0: newer is chunk 1 (4)
+      chunk(std::integral_constant<int, 0>{});
+      tload(std::integral_constant<int, 2>{});             // (chunk 0's registers)
+      E_WAIT4(8, tc[1]);                                   // chunk 1: newer are chunk 0's stores (4) and chunk 2 (4)
+      chunk(std::integral_constant<int, 1>{});
+      tload(std::integral_constant<int, 3>{});
+      E_WAIT4(8, tc[0]);                                   // chunk 2: newer are chunk 1's stores and chunk 3
+      chunk(std::integral_constant<int, 2>{});
+      E_WAIT4(4, tc[1]);                                   // chunk 3: newer are chunk 2's stores
+      chunk(std::integral_constant<int, 3>{});
+      // every wave has read the exchange area before any wave's next tile refills the slot (LDS-DMA in phase 1 of its first K-tile)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      N_BAR();
+      // lane (er, ep) keeps column 32 (er & 1) + 8 ep + (er >> 1) of the wave's 64: three registers run on over the workgroup's tiles
+      run_g += (er & 1) ? tot_g[1] : tot_g[0];
+      run_b += (er & 1) ? tot_b[1] : tot_b[0];
+      run_x += (er & 1) ? tot_x[1] : tot_x[0];
+    } else
     {
       // epilogue addressing (see gemm_bf16_e256): after the column swap lane (li, lq) holds 8 columns of a 32-column block of row li; the values
       // go through one lane transpose in LDS so that four adjacent lanes store 64 contiguous bytes of a row.  Derived HERE from an opaque copy of
@@ -1244,6 +1489,15 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_n512(GemmP p, LnP q) {
     nA = (const unsigned char*)p.A + nm0 * p.lda * 2;
     if (wr == 1) { N_BAR(); }  // the stagger again
   }
+  if constexpr (LNB) {
+    // this workgroup's partial column sums -> work[which][workgroup][512] (plain stores; layernorm_bwd_reduce_k adds the workgroups' rows)
+    const int er = lane >> 2, ep = lane & 3;
+    const int col = 256 * wr + 64 * wc + 32 * (er & 1) + 8 * ep + (er >> 1);
+    float* w = q.work + (size_t)blockIdx.x * 512 + col;
+    w[0] = run_g;
+    w[(size_t)gridDim.x * 512] = run_b;
+    w[(size_t)2 * gridDim.x * 512] = run_x;
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last tile's surplus prefetches land before the LDS is released
 #undef N_RD_A
 #undef N_RD_B
@@ -1262,7 +1516,7 @@ bool pero_launch_gemm_n512(const GemmP& p0, long long batch, bool ta, bool tb, b
   const long long nt = p0.M / N_BM;
   const unsigned G = (unsigned)(nt < num_cus ? ((nt + 7) / 8) * 8 : num_cus);
   GemmP p = p0;
-  const LnP q = {nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0.f};
+  const LnP q = {nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0.f, nullptr};
 #define LAUNCH_N(EP_, BI_)                                                                          \
   do {                                                                                              \
     PERO_LDS_ATTR((gemm_bf16_n512<EP_, BI_>), N_LDS_BYTES);                                          \
@@ -1283,10 +1537,30 @@ bool pero_launch_gemm_n512_ln(const GemmP& p0, void* t, long long ldt, float* me
   const long long nt = p0.M / N_BM;
   const unsigned G = (unsigned)(nt < num_cus ? ((nt + 7) / 8) * 8 : num_cus);
   GemmP p = p0;
-  const LnP q = {t, ldt, mean, rstd, gamma, beta, eps};
+  const LnP q = {t, ldt, mean, rstd, gamma, beta, eps, nullptr};
   if (!p0.C) { if (p0.bias) LAUNCH_N(EP_RESID_LN_T, true); else LAUNCH_N(EP_RESID_LN_T, false); }   // y not stored
   else if (p0.bias) LAUNCH_N(EP_RESID_LN, true); else LAUNCH_N(EP_RESID_LN, false);
 #undef LAUNCH_N
+  return true;
+}
+
+// dx = LayerNorm backward (from the norm's output t and rstd) of dt = A W^T + R, column sums -> work [3][grid][512]; *grid_out = the rows of work that
+// layernorm_bwd_reduce_k has to add.  false: the shape does not take it.
+bool pero_launch_gemm_n512_lnb(const GemmP& p0, const void* t, long long ldt, const float* rstd, const float* gamma, const float* beta, float* work,
+                               int* grid_out, hipStream_t st) {
+  if (p0.N != 512 || p0.M % N_BM || p0.K % E_BK || p0.K < 3 * E_BK || !p0.resid || p0.bias || !p0.C || !t || !rstd || !gamma || !beta || !work) return false;
+  if (p0.lda >= (1LL << 22) || p0.ldb >= (1LL << 22) || p0.ldc >= (1LL << 22) || p0.ldr >= (1LL << 22) || ldt >= (1LL << 22)) return false;
+  int num_cus = (pero_num_cus() / 8) * 8;
+  if (num_cus < 8) num_cus = 8;
+  const long long nt = p0.M / N_BM;
+  const unsigned G = (unsigned)(nt < num_cus ? ((nt + 7) / 8) * 8 : num_cus);
+  // (workgroups beyond the tile count return at once: their rows of `work` are cleared first - the reduce kernel adds all G rows)
+  if (nt < (long long)G) hipMemsetAsync(work, 0, (size_t)3 * G * 512 * sizeof(float), st);
+  GemmP p = p0;
+  const LnP q = {const_cast<void*>(t), ldt, nullptr, const_cast<float*>(rstd), gamma, beta, 0.f, work};
+  PERO_LDS_ATTR((gemm_bf16_n512<EP_RESID_LNB, false>), N_LDS_BYTES);
+  hipLaunchKernelGGL((gemm_bf16_n512<EP_RESID_LNB, false>), dim3(G), dim3(512), N_LDS_BYTES, st, p, q);
+  *grid_out = (int)G;
   return true;
 }
 

@@ -1,7 +1,7 @@
 // Row-wise HBM-bound kernels: LayerNorm (+positional encoding) fwd/bwd, softmax fwd/bwd, masked
 // cross entropy, column sums.  One 64-lane wave per row (shuffle reductions, no LDS for the row
 // statistics), 16-byte global accesses, f32 statistics whatever the storage dtype.
-#include "common.hpp"
+#include "gemm_common.hpp"
 
 // ---------------------------------------------------------------------------------------------
 // LayerNorm forward.  d % 8 == 0, d <= 512 * NCH.  4 waves per block, one row per wave.
@@ -328,6 +328,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_reduce_k(const float* work,
   red[part][c] = s;
   __syncthreads();
   if (part == 0 && col < d) dst[col] += (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+}
+
+void pero_ln_bwd_reduce_launch(const float* work, float* dgamma, float* dbeta, float* dxsum, int nblocks, int d, hipStream_t st) {
+  hipLaunchKernelGGL(layernorm_bwd_reduce_k, dim3((unsigned)((d + 63) / 64), 3), dim3(256), 0, st, work, dgamma, dbeta, dxsum, nblocks, d);
 }
 
 template <typename T>

@@ -220,6 +220,21 @@ def linear_resid_ln_fwd(x, lin_w, lin_b, resid, norm, dtype, keep_y=True):
     return (y if keep_y else None), t, mean, rstd
 
 
+FUSE_LN_BWD = True    # bf16 mode with LN_BWD_FROM_OUT: the LayerNorm backward of norm1 / norm2 runs in the epilogue of the input-gradient product that
+                      # produces its upstream gradient (linear1's dX -> norm1, in_proj's dX -> the PREVIOUS layer's norm2) - one launch on the
+                      # row-complete tile (pero_gemm_resid_layernorm_bwd), dt never stored
+
+
+def linear_bwd_ln(dy, x, w, b, dtype, residual, t_ln, rstd_ln, norm, dxsum, side=None, bias_grad_done=False):
+    """linear_bwd(dy, x, w, b, residual=residual) followed by the LayerNorm backward (from its output t_ln and rstd_ln) of `norm`, whose output
+    x is: returns dy_norm.  Fused into one launch where the shape allows; None if it does not (the caller runs the pair)."""
+    if not (FUSE_LN_BWD and DX_ON_WT and dtype == torch.bfloat16 and ops.gemm_resid_layernorm_bwd_ok(dy, lowp.weight_t(w), residual, t_ln)):
+        return None
+    linear_bwd(dy, x, w, b, dtype, need_dx=False, side=side, bias_grad_done=bias_grad_done)   # weight (and bias) gradients
+    return ops.gemm_resid_layernorm_bwd(dy, lowp.weight_t(w), residual, t_ln, rstd_ln, norm.weight.detach(), norm.bias.detach(),
+                                        ensure_grad(norm.weight), ensure_grad(norm.bias), dxsum)
+
+
 def ln_bwd(dt, y, t, mean, rstd, norm, dxsum):
     """LayerNorm backward of an encoder layer's norm: from the saved input rows y, or - when the forward did not keep them - from its output t."""
     if y is None:
@@ -246,17 +261,25 @@ def layer_fwd(t, L, n, s, h, dtype, save):
     return t2, saved
 
 
-def layer_bwd(dt2, L, saved, n, s, h, dtype, side=None):
+def layer_bwd(dt2, L, saved, n, s, h, dtype, side=None, dt2_is_dy2=False, prev=None):
+    """dt2: gradient of the layer's output - or, with dt2_is_dy2, already the gradient behind norm2's backward (the layer above ran it in the
+    epilogue of its last product).  prev = (rstd2, layer) of the layer BELOW: its norm2's backward is then fused into this layer's last product
+    where the shape allows.  Returns (gradient for the layer below, whether that is already behind the lower layer's norm2 backward)."""
     t, qkv, p, a, y1, mean1, rstd1, t1, hdn, y2, mean2, rstd2, bits, t2 = saved
     at = L.self_attn
     # LN2 (its dx column sums are linear2's bias gradient)
-    dy2 = ln_bwd(dt2, y2, t2, mean2, rstd2, L.norm2, ensure_grad(L.linear2.bias))
+    dy2 = dt2 if dt2_is_dy2 else ln_bwd(dt2, y2, t2, mean2, rstd2, L.norm2, ensure_grad(L.linear2.bias))
     # linear1's bias gradient = column sums of dpre1: accumulated by the epilogue of the product that writes dpre1
     fuse_b1 = FUSE_BIAS_GRAD and FUSE_B1_COLSUM and dtype == torch.bfloat16 and L.linear1.bias is not None and L.linear1.bias.requires_grad
     dpre1 = linear_bwd(dy2, hdn, L.linear2.weight, L.linear2.bias, dtype, gate=hdn, gate_bits=bits, bias_grad_done=True, side=side,
                        dx_colsum_into=ensure_grad(L.linear1.bias) if fuse_b1 else None)
-    dt1 = linear_bwd(dpre1, t1, L.linear1.weight, L.linear1.bias, dtype, residual=dy2, side=side, bias_grad_done=fuse_b1)
-    dy1 = ln_bwd(dt1, y1, t1, mean1, rstd1, L.norm1, ensure_grad(at.out_proj.bias))
+    dy1 = None
+    if y1 is None:   # norm1's backward in the epilogue of linear1's input-gradient product
+        dy1 = linear_bwd_ln(dpre1, t1, L.linear1.weight, L.linear1.bias, dtype, dy2, t1, rstd1, L.norm1, ensure_grad(at.out_proj.bias),
+                            side=side, bias_grad_done=fuse_b1)
+    if dy1 is None:
+        dt1 = linear_bwd(dpre1, t1, L.linear1.weight, L.linear1.bias, dtype, residual=dy2, side=side, bias_grad_done=fuse_b1)
+        dy1 = ln_bwd(dt1, y1, t1, mean1, rstd1, L.norm1, ensure_grad(at.out_proj.bias))
     fused_attn = p.dim() == 2
     dvec = None
     if fused_attn and FUSE_ROWDOT and a.shape[1] % 128 == 0:
@@ -271,7 +294,13 @@ def layer_bwd(dt2, L, saved, n, s, h, dtype, side=None):
         dqkv = ops.attention_bwd_fused(qkv, a, da, p, n, s, h, dbias=ensure_grad(at.in_proj_bias) if fuse_bq else None, dvec=dvec)
     else:
         dqkv = attention_bwd(qkv, p, da, n, s, h)
-    return linear_bwd(dqkv, t, at.in_proj_weight, at.in_proj_bias, dtype, residual=dy1, side=side, bias_grad_done=fuse_bq)
+    if prev is not None:   # the lower layer's norm2 (its output is this layer's input t) in the epilogue of in_proj's input-gradient product
+        rstd2_prev, Lp = prev
+        dy2_prev = linear_bwd_ln(dqkv, t, at.in_proj_weight, at.in_proj_bias, dtype, dy1, t, rstd2_prev, Lp.norm2, ensure_grad(Lp.linear2.bias),
+                                 side=side, bias_grad_done=fuse_bq)
+        if dy2_prev is not None:
+            return dy2_prev, True
+    return linear_bwd(dqkv, t, at.in_proj_weight, at.in_proj_bias, dtype, residual=dy1, side=side, bias_grad_done=fuse_bq), False
 
 
 # ---------------------------------------------------------------------------------------------
@@ -316,8 +345,12 @@ def backbone_bwd(mod, saved, dt, dtype, on_layer_done=None):
     a0, y0, mean0, rstd0, layers, n, s = saved
     nl = len(layers)
     side = SideStream(dt.device)
+    is_dy2 = False
     for i in range(nl - 1, -1, -1):
-        dt = layer_bwd(dt, mod.encoder_layers.layers[i], layers[i], n, s, mod.num_heads, dtype, side)
+        prev = None
+        if i > 0 and layers[i - 1][9] is None:   # the lower layer kept no pre-norm rows: its norm2 backward runs from its output (= this layer's input)
+            prev = (layers[i - 1][11], mod.encoder_layers.layers[i - 1])
+        dt, is_dy2 = layer_bwd(dt, mod.encoder_layers.layers[i], layers[i], n, s, mod.num_heads, dtype, side, dt2_is_dy2=is_dy2, prev=prev)
         layers[i] = None
         if on_layer_done is not None:
             with side.comm_context():  # sees the layer's gradient kernels on the main and the side streams

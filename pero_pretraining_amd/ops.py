@@ -159,6 +159,32 @@ def gemm_resid_layernorm(a, w, bias, residual, gamma, beta, eps, store_y=True):
     return y, t, mean, rstd
 
 
+def gemm_resid_layernorm_bwd_ok(a, w_t, residual, t):
+    """Shapes the fused input-gradient + LayerNorm-backward launch takes (csrc/gemm_e.hip gemm_bf16_n512, EP_RESID_LNB)."""
+    return (a.dtype == torch.bfloat16 and a.dim() == 2 and w_t.dim() == 2 and w_t.shape[0] == 512 and a.shape[0] % 128 == 0 and a.shape[1] % 64 == 0 and
+            a.shape[1] >= 192 and a.shape[1] == w_t.shape[1] and residual is not None and residual.shape == (a.shape[0], 512) and
+            t is not None and t.shape == (a.shape[0], 512) and a.stride(1) == 1 and w_t.stride(1) == 1 and residual.stride(1) == 1 and t.stride(1) == 1 and
+            a.stride(0) % 8 == 0 and w_t.stride(0) % 8 == 0 and residual.stride(0) % 8 == 0 and t.stride(0) % 8 == 0)
+
+
+def gemm_resid_layernorm_bwd(a, w_t, residual, t, rstd, gamma, beta, dgamma, dbeta, dxsum=None):
+    """dx = LayerNorm backward (from the norm's output t and rstd) of dt = a @ w_t^T + residual, dt never stored; dgamma / dbeta / dxsum are
+    accumulated into - ONE launch + the small column-sum reduce (pero_gemm_resid_layernorm_bwd)."""
+    _req_cuda(a)
+    M, K = a.shape
+    dx = torch.empty((M, 512), device=a.device, dtype=torch.bfloat16)
+    work = torch.empty(3 * _lib.LN_BWD_BLOCKS * 512, device=a.device, dtype=torch.float32)
+    if gemm_timeline is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    call("pero_gemm_resid_layernorm_bwd", ptr(a), ptr(w_t), ptr(residual), ptr(t), ptr(rstd), ptr(gamma), ptr(beta), ptr(dx), ptr(dgamma), ptr(dbeta),
+         ptr(dxsum), ptr(work), M, 512, K, a.stride(0), w_t.stride(0), residual.stride(0), t.stride(0), dx.stride(0), stream())
+    if gemm_timeline is not None:   # the product's flops over the WHOLE launch (LayerNorm backward and the reduce included)
+        e1.record()
+        gemm_timeline.append((e0, e1, 2.0 * M * 512 * K, "gemm_bf16_tile:NN"))
+    return dx
+
+
 def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, dxsum=None):
     rows, d = x.shape
     dx = torch.empty_like(x)

@@ -255,3 +255,52 @@ def test_fused_linear_residual_layernorm(e256, M, K):
         # the launch that does not store y (the backward then reads t: pero_layernorm_bwd_out): the same t, mean, rstd, bit for bit
         yn, tn, mn, rn = ops.gemm_resid_layernorm(x, w, b, res, gamma, beta, 1e-5, store_y=False)
         assert yn is None and torch.equal(tn, t) and torch.equal(mn, mean) and torch.equal(rn, rstd)
+
+
+@pytest.mark.parametrize("M,K", [(1024, 192), (2176, 1536), (131072 + 384, 2048), (65536, 512)])
+def test_fused_input_gradient_layernorm_backward(e256, M, K):
+    """pero_gemm_resid_layernorm_bwd (gemm_bf16_n512 with the LayerNorm-BACKWARD epilogue): dx, dgamma, dbeta, dxsum = what the pair
+    pero_gemm (residual epilogue; dt stored in bf16) + pero_layernorm_bwd_out computes - the fused launch rounds dt the same way and uses the
+    same formulas, only the summation orders of the row and column sums differ (a few dx per thousand by one bf16 step; column sums 1e-5 of
+    their range); repeatable; strided operands; the column sums ACCUMULATE into their destinations."""
+    ops = e256
+    from pero_pretraining_amd import _lib
+    L = _lib.lib()
+    torch.manual_seed(17 + K)
+    dy = (torch.randn(M, K + 64, device="cuda") * 0.5).bfloat16()[:, 64:]          # a column-slice view: lda > K
+    wt = (torch.randn(512, K, device="cuda") * 0.05).bfloat16()
+    res = torch.randn(M, 512 + 128, device="cuda").bfloat16()[:, :512]
+    gamma = torch.rand(512, device="cuda") + 0.5
+    gamma[5::11] *= -1.0
+    beta = torch.randn(512, device="cuda") * 0.2
+    y = (torch.randn(M, 512, device="cuda") * 1.5 + 0.2).bfloat16()
+    t, mean, rstd = ops.layernorm_fwd(y, gamma, beta, 1e-5)
+    assert ops.gemm_resid_layernorm_bwd_ok(dy, wt, res, t)
+    try:
+        L.pero_set_option(b"gemm_nw", 1)      # the unfused product on the same tile kernel (it takes M % 128 == 0)
+        dt = ops.gemm(dy, wt, residual=res)
+    finally:
+        L.pero_set_option(b"gemm_nw", 0)
+    dg0, db0, dx0s = (torch.zeros(512, device="cuda") for _ in range(3))
+    dx0 = ops.layernorm_bwd_out(dt, t, rstd, gamma, beta, dg0, db0, dx0s)
+    init = torch.arange(512, device="cuda", dtype=torch.float32) * 0.25
+    dg, db, dxs = init.clone(), init.clone(), init.clone()
+    dx = ops.gemm_resid_layernorm_bwd(dy, wt, res, t, rstd, gamma, beta, dg, db, dxs)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(dx.float()).all())
+    d = (dx.float() - dx0.float()).abs()
+    top = float(dx0.float().abs().max())
+    assert float(d.max()) <= 2 ** -7 * top, (float(d.max()), top)
+    assert int((d > 0).sum()) <= 2e-2 * dx.numel(), int((d > 0).sum())
+    for got, want, name in ((dg - init, dg0, "dgamma"), (db - init, db0, "dbeta"), (dxs - init, dx0s, "dxsum")):
+        assert float((got - want).abs().max()) <= 2e-4 * max(1.0, float(want.abs().max())), name
+    # ... and against f64 arithmetic on the stored dt
+    xh = ((t.double() - beta.double()) / gamma.double())
+    g = dt.double() * gamma.double()
+    ref = rstd.double()[:, None] * (g - g.mean(1, keepdim=True) - xh * (g * xh).mean(1, keepdim=True))
+    assert float((dx.double() - ref).abs().max()) <= 2 ** -7 * float(ref.abs().max())
+    assert float((dg - init - (dt.double() * xh).sum(0).float()).abs().max()) <= 1e-3 * float((dt.double() * xh).sum(0).abs().max())
+    for _ in range(3):
+        dg2, db2, dxs2 = init.clone(), init.clone(), init.clone()
+        again = ops.gemm_resid_layernorm_bwd(dy, wt, res, t, rstd, gamma, beta, dg2, db2, dxs2)
+        assert torch.equal(again, dx) and torch.equal(dg2, dg) and torch.equal(db2, db) and torch.equal(dxs2, dxs)
