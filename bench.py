@@ -17,8 +17,11 @@ zero_grad -> front end (u8 -> /255 -> mask tile -> patches) -> 12 encoder layers
   resident_step       the same without prepare_batch in the timed region (labels and mask resident too: train_step_prepared only)
   with_h2d            prepare_batch INCLUDING the uint8 batch from pinned host memory over PCIe (copy stream, double-buffered) - never `value`
   roofline            the bf16 tile GEMM: algorithmic flops / HIP-event duration of every launch of two extra steps
-  legs                configs[2] (codebook argmin), configs[3] (VICReg step; under N > 1 with data-parallel gradients, per-rank and exact
-                      global statistics), configs[4] (NT-Xent step, 512 lines per GPU; under N > 1 with cross-rank negatives)
+  hbm_kernels         the bandwidth-bound kernels of the step alone at the step's shapes (HIP events): algorithmic GB, us, TB/s, fraction of 8 TB/s
+  batch_sweep         the same step at 16 / 64 / 128 / 1024 lines per GPU (the reference's default --batch-size is 16), eager and as a hipGraph
+  legs                configs[2] (codebook argmin alone, and the V = 8192 masked step with its labels from the argmin inside the step), configs[3]
+                      (VICReg step; under N > 1 with data-parallel gradients, per-rank and exact global statistics), configs[4] (NT-Xent step,
+                      512 lines per GPU; under N > 1 with cross-rank negatives)
   cpu_baseline        the CPU oracle (oracle/pero_oracle.py, a "port") on the host cores, a bounded sample of the same workload
 """
 import argparse
@@ -83,6 +86,23 @@ def pmc_traffic(batch):
             continue
         if int(d.get("lines_per_gpu", -1)) == int(batch) and d.get("csrc_sha256") == here:
             return d.get("hbm_bytes_per_launch"), name
+    return None, None
+
+
+def pmc_leg_traffic(leg):
+    """HBM bytes per launch of a leg's dominant kernel family from the committed profiles/*pmc_legs_traffic.json (tools/pmc_legs.sh: separate
+    FETCH_SIZE / WRITE_SIZE passes of `bench.py --legs-only --leg <name>`), quoted only for exactly these kernel sources; else (None, None)."""
+    here = csrc_hash()
+    for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
+        if not name.endswith("pmc_legs_traffic.json"):
+            continue
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                d = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if d.get("csrc_sha256") == here and leg in d.get("legs", {}):
+            return d["legs"][leg].get("hbm_bytes_per_launch"), name
     return None, None
 
 
@@ -257,7 +277,170 @@ def gemm_roofline(per, nsteps, step_seconds, traffic):
                               "launches_per_step": v[2] // nsteps} for k, v in sorted(per.items())}}
 
 
+HBM_PEAK_TBS = 8.0   # MI355X_MICROARCH.md "HBM3E peak BW" (spec; 6.3 TB/s is what a float4 copy reaches)
+
+
+def hbm_kernels(device, batch):
+    """The bandwidth-bound kernels of the step (front end, LayerNorm, Adam, attention at S = 256), each alone at the step's shapes,
+    timed with HIP events on the launching stream: algorithmic bytes / median duration, against the 8 TB/s of the data sheet."""
+    from pero_pretraining_amd import ops
+    S, d, h = CFG["width"] // CFG["patch"], CFG["model_dim"], CFG["num_heads"]
+    rows = batch * S
+    g = torch.Generator(device=device).manual_seed(11)
+
+    def timed(fn, n=8, rounds=3):
+        """median over `rounds` of (n back-to-back launches between one pair of HIP events) / n"""
+        for _ in range(3):
+            fn()
+        evs = []
+        for _ in range(rounds):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n):
+                fn()
+            e1.record()
+            evs.append((e0, e1))
+        torch.cuda.synchronize()
+        return statistics.median(a.elapsed_time(b) for a, b in evs) * 1e-3 / n
+
+    out = {}
+
+    def add(name, seconds, nbytes, note):
+        out[name] = {"gb": round(nbytes / 1e9, 3), "us": round(seconds * 1e6, 1), "tb_per_s": round(nbytes / seconds / 1e12, 2),
+                     "frac_of_8_tb_per_s": round(nbytes / seconds / 1e12 / HBM_PEAK_TBS, 3), "bytes": note}
+
+    # front end: u8 images -> patch rows (bf16, pitch 1024)
+    images = torch.randint(0, 256, (batch, CFG["height"], CFG["width"], CFG["channels"]), device=device, dtype=torch.uint8, generator=g)
+    mask = (torch.rand(batch, S, device=device, generator=g) < 0.15).long()
+    tile = torch.rand(CFG["channels"], CFG["height"], CFG["patch"], device=device, generator=g)
+    kp = CFG["channels"] * CFG["height"] * CFG["patch"]
+    pitch = ((kp + 127) // 128) * 128
+    t = timed(lambda: ops.patches_from_u8(images, mask, tile, CFG["patch"], torch.bfloat16, pitch))
+    add("patches_u8 (front end)", t, images.numel() + rows * pitch * 2, "u8 image read + bf16 patch rows (pitch 1024) written")
+    del images
+    x = torch.randn(rows, d, device=device, generator=g).bfloat16()
+    dy = torch.randn(rows, d, device=device, generator=g).bfloat16()
+    gamma = torch.rand(d, device=device, generator=g) + 0.5
+    beta = torch.randn(d, device=device, generator=g) * 0.1
+    pe = torch.randn(4096, d, device=device, generator=g)
+    offs = torch.randint(0, 4096 - S, (batch,), device=device, generator=g)
+    t = timed(lambda: ops.layernorm_fwd(x, gamma, beta, 1e-5, pe=pe, offsets=offs, S=S))
+    add("layernorm_fwd (+ positional rows)", t, rows * d * 2 * 2, "bf16 rows read + written (the f32 positional rows come from the Infinity Cache)")
+    y, mean, rstd = ops.layernorm_fwd(x, gamma, beta, 1e-5)
+    dg, db, dxs = (torch.zeros(d, device=device) for _ in range(3))
+    t = timed(lambda: ops.layernorm_bwd(dy, x, mean, rstd, gamma, dg, db, dxs))
+    add("layernorm_bwd (from the input rows) + reduce", t, rows * d * 2 * 3, "dy, x read + dx written")
+    t = timed(lambda: ops.layernorm_bwd_out(dy, y, rstd, gamma, beta, dg, db, dxs))
+    add("layernorm_bwd_out (from the output rows) + reduce", t, rows * d * 2 * 3, "dy, t read + dx written")
+    del x, dy, y
+    # fused Adam over the flat parameter buffer (config-2 size)
+    n = 40422912
+    pflat, gflat, m, v = (torch.randn(n, device=device, generator=g) * 0.01 for _ in range(4))
+    v.abs_()
+    pb = torch.empty(n, device=device, dtype=torch.bfloat16)
+    t = timed(lambda: ops.adam_step(pflat, gflat, m, v, pb, 1e-4, 0.9, 0.999, 1e-8, 10))
+    add("adam_k (fused, + bf16 weight copy)", t, n * (16 + 14), "p, g, m, v read (16 B) + p, m, v, bf16 copy written (14 B) per parameter")
+    del pflat, gflat, m, v, pb
+    # attention of one layer
+    qkv = (torch.randn(rows, 3 * d, device=device, generator=g) * 0.5).bfloat16()
+    t = timed(lambda: ops.attention_fwd_fused(qkv, batch, S, h))
+    add("attention forward (one layer)", t, rows * (3 * d + d) * 2, "qkv read + out written (lse: 2 %)")
+    out_, lse = ops.attention_fwd_fused(qkv, batch, S, h)
+    dout = (torch.randn(rows, d, device=device, generator=g) * 0.1).bfloat16()
+    dvec = (out_.float() * dout.float()).view(rows, h, d // h).sum(-1).contiguous()
+    dbias = torch.zeros(3 * d, device=device)
+    t = timed(lambda: ops.attention_bwd_fused(qkv, out_, dout, lse, batch, S, h, dbias=dbias, dvec=dvec))
+    add("attention backward (one layer, D handed in)", t, rows * (3 * d + d + 3 * d) * 2, "qkv, dout read + dqkv written")
+    return out
+
+
+def batch_sweep(device, model, opt, sched, bf16, rank, timer, world):
+    """The headline step at small per-GPU batches (the reference's default is --batch-size 16, masked_pretraining/train.py:30):
+    labels and mask resident, eager launches and - where a step is launch-bound - the same step replayed as a hipGraph."""
+    from pero_pretraining_amd.masked_pretraining.batch_operator import BatchOperator
+    from pero_pretraining_amd.masked_pretraining.trainer import Trainer
+    res = {}
+    for B in (16, 64, 128, 1024):
+        batches = synthetic(rank, B, device)
+        entry = {}
+        for mode in (("eager", "hip_graph") if B <= 128 else ("eager",)):
+            tr = Trainer(BatchOperator(device, 0.15), model, None, opt, sched, bfloat16=bf16, hip_graph=(mode == "hip_graph"))
+
+            def step(i):
+                sched.update_learning_rate(i)
+                b = batches[i % len(batches)]
+                return tr.train_step_prepared(b["images"], b["labels_dev"], b["mask_dev"])
+            for i in range(3):
+                step(i)
+            steps = 30 if B <= 128 else 10
+            el, rp, _ = timer.median(step, steps, 3, first=3)
+            lps = world * B * steps / el
+            entry[mode] = {"value": round(lps, 1), "unit": "lines/s", "ms_per_step": round(el / steps * 1e3, 3),
+                           "step_mfma_frac_formula_flops": round(lps / world * flops_per_line() / (BF16_MFMA_PEAK_TFLOPS * 1e12), 4)}
+            del tr
+        res[f"B={B}"] = entry
+        del batches
+    res["note"] = ("labels and mask resident (train_step_prepared); 3 repeats of 30 (B <= 128) / 10 steps, median; hip_graph = Trainer(hip_graph=True): "
+                   "zero_grad + forward + backward replayed as one graph, dense head backward")
+    return res
+
+
 # ------------------------------------------------------------------------------------------------ legs
+def leg_config3_step(timer, device, batch, steps, repeats, rank, world):
+    """BASELINE.json configs[2] as a STEP: the masked step with a V = 8192 head whose labels are produced INSIDE the step by the codebook argmin
+    (pero_vq_argmin, K = 8192 x D = 512, exact f32) from resident encoder features (SURVEY.md 8d: synthetic standard-normal features and codebook;
+    the tokenizer's VGG encoder is out of scope)."""
+    from pero_pretraining_amd import ops
+    from pero_pretraining_amd.common.lr_scheduler import WarmupSchleduler
+    from pero_pretraining_amd.masked_pretraining import model as M
+    from pero_pretraining_amd.masked_pretraining.batch_operator import BatchOperator
+    from pero_pretraining_amd.masked_pretraining.trainer import Trainer
+    from pero_pretraining_amd.optim import FusedAdam
+    torch.manual_seed(0)
+    V = 8192
+    bb = M.init_backbone({"type": "vit", "num_blocks": CFG["num_blocks"], "model_dim": CFG["model_dim"], "num_heads": CFG["num_heads"],
+                          "feedforward_dim": CFG["feedforward_dim"]})
+    hd = M.init_head({"in_features": CFG["model_dim"], "out_features": V})
+    model = M.MaskedTransformerEncoder(bb, hd).to(device).train()
+    opt = FusedAdam(model.parameters(), lr=2e-4)
+    sched = WarmupSchleduler(opt, 2e-4, 10000, 1)
+    tr = Trainer(BatchOperator(device, 0.15), model, None, opt, sched, bfloat16=True)
+    S = CFG["width"] // CFG["patch"]
+    rng = np.random.default_rng(77 + rank)
+    images = torch.from_numpy(rng.integers(0, 256, (batch, CFG["height"], CFG["width"], CFG["channels"]), dtype=np.uint8)).to(device)
+    g = torch.Generator(device=device).manual_seed(3 + rank)
+    feats = torch.randn(batch * S, 512, device=device, generator=g)
+    code = torch.randn(V, 512, device=device, generator=g)
+    mask_h = (rng.random((batch, S)) < 0.15).astype(np.int64)
+    mask = torch.from_numpy(mask_h).to(device)
+    mask._pero_host = mask_h
+
+    def step(i):
+        sched.update_learning_rate(i)
+        labels = ops.vq_argmin(feats, code).view(batch, S)      # the tokenizer's quantizer: labels of this batch, on the device
+        return tr.train_step_prepared(images, labels, mask)
+    for i in range(2):
+        step(i)
+    med, els, loss_v = timer.median(step, steps, repeats, first=2)
+    evs = []
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); ops.vq_argmin(feats, code); e1.record()
+        evs.append((e0, e1))
+    torch.cuda.synchronize()
+    t_arg = statistics.median(a.elapsed_time(b) for a, b in evs) * 1e-3
+    cfg3 = dict(CFG, vocab=V)
+    fl = flops_per_line(cfg3) + 2.0 * S * V * 512
+    lps = world * batch * steps / med
+    del model, opt, tr
+    return {"workload": f"masked step with a V = 8192 head, labels = codebook argmin (8192 x 512, f32 exact) of resident features INSIDE the step, "
+                        f"{batch} lines of 40x2048 per GPU, bf16 (BASELINE.json configs[2])",
+            "ms_per_step": round(med / steps * 1e3, 3), "lines_per_s": round(lps, 1), "repeats_ms_per_step": [round(e / steps * 1e3, 3) for e in els],
+            "argmin_ms_of_it": round(t_arg * 1e3, 3), "loss": round(float(loss_v.detach()), 5),
+            "gflop_per_line_step": round(fl / 1e9, 3),
+            "note": "the argmin's 2 S K D flops per line run on the exact f32 MFMA (157 TFLOP/s peak): the step's bf16 MFMA fraction is not quoted for the sum"}
+
+
 def leg_config3(timer, device):
     """BASELINE.json configs[2]: codebook argmin of the VQ tokenizer, K = 8192 codes x D = 512, the rows of 128 lines."""
     from pero_pretraining_amd import ops
@@ -275,11 +458,12 @@ def leg_config3(timer, device):
     torch.cuda.synchronize()
     t = statistics.median(a.elapsed_time(b) for a, b in evs) * 1e-3
     ach = 2.0 * M * K * D / t / 1e12
+    traffic, tsrc = pmc_leg_traffic("config3_vq_argmin")
     return {"workload": "VQ codebook argmin (BASELINE.json configs[2]): 32768 rows (128 lines x 256) x 8192 codes x 512, f32 exact",
             "ms": round(t * 1e3, 3), "lines_per_s": round(M / 256 / t, 1), "rows_per_s": round(M / t, 1),
             "roofline": {"bound": "mfma", "kernel": "vq_argmin_fast_k (v_mfma_f32_32x32x2_f32, running argmin in registers)",
                          "achieved": round(ach, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4),
-                         "traffic": None}}
+                         "traffic": traffic, "traffic_source": f"profiles/{tsrc}" if tsrc else None}}
 
 
 def leg_joint(timer, device, kind, pairs, steps, repeats, world, rank, variant=None):
@@ -321,7 +505,10 @@ def leg_joint(timer, device, kind, pairs, steps, repeats, world, rank, variant=N
         tr.train_step_prepared(*prepared)
     med, els, loss_v = timer.median(lambda i: tr.train_step_prepared(*prepared), steps, repeats)
     per = timed_gemms(lambda n: [tr.train_step_prepared(*prepared) for _ in range(n)], 1)
-    roof = gemm_roofline(per, 1, med / steps, None)
+    leg_name = ("config4_vicreg_step" if kind == "vicreg" else "config5_ntxent_step") if world == 1 else None
+    traffic, tsrc = pmc_leg_traffic(leg_name) if leg_name else (None, None)
+    roof = gemm_roofline(per, 1, med / steps, traffic)
+    roof["traffic_source"] = f"profiles/{tsrc}" if tsrc else None
     del model, opt, tr
     name = "VICReg" if kind == "vicreg" else "NT-Xent"
     return {"workload": f"{name} joint-embedding step, 12-layer d=512 ViT + linear head 4096, {pairs} line pairs of 40x2048 per GPU, bf16 "
@@ -349,6 +536,9 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the config 3 / 4 / 5 legs")
     ap.add_argument("--legs-only", action="store_true", help="only the config 3 / 4 / 5 legs (profiling)")
+    ap.add_argument("--leg", default=None, help="with --legs-only: only this leg (config3_vq_argmin, config3_masked_step, config4_vicreg_step, config5_ntxent_step)")
+    ap.add_argument("--leg-pairs", default="128,512", help="line pairs per GPU of the config 4 / config 5 legs (the tests' rehearsal shrinks them)")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the small-batch sweep and the bandwidth-bound kernel block")
     ap.add_argument("--dp-no-overlap", action="store_true", help="data parallel: reduce all gradients after the backward pass (A/B of the bucket hooks)")
     ap.add_argument("--dp-layers-per-bucket", type=int, default=2)
     ap.add_argument("--no-options", action="store_true", help="skip the extra legs (resident step, PCIe-inclusive step, masked head)")
@@ -453,7 +643,7 @@ def main():
         out.update({
             "value": round(lines_per_s, 2), "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "config": {"workload": "masked pretraining step incl. prepare_batch, 12-layer d=512 h=4 ff=2048 ViT, V=4096, 40x2048 u8 lines "
-                                   "(BASELINE.json configs[1])",
+                                   "(BASELINE.json configs[1]); uint8 images resident in HBM, the PCIe-inclusive rate is `with_h2d`",
                        "lines_per_gpu": args.batch, "global_batch": args.batch * world, "seq_len": S,
                        "parallelism": f"dp{world}", "optimizer": "fused Adam (f32 master weights)",
                        "weight_gradients_on_side_stream": bool(F.SIDE_STREAM_DW), "head_rows": model.head_rows,
@@ -520,20 +710,34 @@ def main():
             traffic, src = pmc_traffic(args.batch)
             out["roofline"] = gemm_roofline(per, 2, elapsed / args.steps, traffic)
             out["roofline"]["traffic_source"] = f"profiles/{src} (csrc_sha256 {csrc_hash()})" if src else None
-        del batches, model, opt, trainer
+        del batches
+        if not args.no_sweep and not args.masked_head:
+            out["batch_sweep"] = batch_sweep(device, model, opt, sched, bf16, rank, timer, world)
+        del model, opt, trainer
         torch.cuda.empty_cache()   # the masked model's 48 GB of saved activations
+        if not args.no_sweep and rank == 0:
+            out["hbm_kernels"] = hbm_kernels(device, args.batch)
+            torch.cuda.empty_cache()
 
     if not args.no_legs:
         reps = min(args.repeats, 3)
         legs = {}
+        vp, npairs = (int(v) for v in args.leg_pairs.split(","))
         if world == 1:
-            legs["config3_vq_argmin"] = leg_config3(timer, device)
-            legs["config4_vicreg_step"] = leg_joint(timer, device, "vicreg", 128, 5, reps, world, rank)
-            legs["config5_ntxent_step"] = leg_joint(timer, device, "ntxent", 512, 3, reps, world, rank)
+            want = lambda name: args.leg is None or args.leg == name
+            if want("config3_vq_argmin"):
+                legs["config3_vq_argmin"] = leg_config3(timer, device)
+            if want("config3_masked_step"):
+                legs["config3_masked_step"] = leg_config3_step(timer, device, args.batch, 5, reps, rank, world)
+                torch.cuda.empty_cache()
+            if want("config4_vicreg_step"):
+                legs["config4_vicreg_step"] = leg_joint(timer, device, "vicreg", vp, 5, reps, world, rank)
+            if want("config5_ntxent_step"):
+                legs["config5_ntxent_step"] = leg_joint(timer, device, "ntxent", npairs, 3, reps, world, rank)
         else:
-            legs["config4_vicreg_dp"] = leg_joint(timer, device, "vicreg", 128, 5, reps, world, rank)
-            legs["config4_vicreg_dp_global_statistics"] = leg_joint(timer, device, "vicreg", 128, 5, reps, world, rank, variant="global")
-            legs["config5_ntxent_dp_cross_rank_negatives"] = leg_joint(timer, device, "ntxent", 512, 3, reps, world, rank, variant="cross")
+            legs["config4_vicreg_dp"] = leg_joint(timer, device, "vicreg", vp, 5, reps, world, rank)
+            legs["config4_vicreg_dp_global_statistics"] = leg_joint(timer, device, "vicreg", vp, 5, reps, world, rank, variant="global")
+            legs["config5_ntxent_dp_cross_rank_negatives"] = leg_joint(timer, device, "ntxent", npairs, 3, reps, world, rank, variant="cross")
         out["legs"] = legs
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.legs_only:

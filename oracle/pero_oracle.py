@@ -354,7 +354,7 @@ def ntxent_cross_loss(x, y, lines_per_rank, temperature=0.1):
     for l in range(x.shape[0]):
         sim = (xn[l] @ yn[l].t()) / temperature                      # [i, j]
         neg = (p @ yn[l].t()) / temperature                          # [l', j]
-        keep = torch.ones(x.shape[0], dtype=torch.bool)
+        keep = torch.ones(x.shape[0], dtype=torch.bool, device=x.device)
         keep[l] = False
         denom = torch.exp(sim).sum(dim=0) + torch.exp(neg[keep]).sum(dim=0)
         losses.append((torch.log(denom) - torch.diag(sim)).mean())

@@ -1240,8 +1240,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_n512(GemmP p, LnP q) {
 #pragma unroll
           for (int e = 0; e < 4; e++) {
             G[e] = Gp(hb, e); Bt[e] = Bp(hb, e);
-            IG[e][0] = G[e][0] != 0.f ? 1.0f / G[e][0] : 0.f;
-            IG[e][1] = G[e][1] != 0.f ? 1.0f / G[e][1] : 0.f;
+            // (v_rcp_f32, one ulp: the correctly rounded quotient is a dozen instructions per column and tile)
+            IG[e][0] = G[e][0] != 0.f ? __builtin_amdgcn_rcpf(G[e][0]) : 0.f;
+            IG[e][1] = G[e][1] != 0.f ? __builtin_amdgcn_rcpf(G[e][1]) : 0.f;
             AG[e] = (ef2v){0.f, 0.f}; AB[e] = (ef2v){0.f, 0.f}; AX[e] = (ef2v){0.f, 0.f};
           }
         }
@@ -1274,15 +1275,15 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_n512(GemmP p, LnP q) {
           tot_x[hb] = colred8(AX);
         }
       };
-      E_WAIT4(4, tc[0]);                                   // chunk 0: newer is chunk 1 (4)
+      E_WAIT4(4, tc[0]);                       // chunk 0: newer is chunk 1 (4)
       chunk(std::integral_constant<int, 0>{});
       tload(std::integral_constant<int, 2>{});             // (chunk 0's registers)
-      E_WAIT4(8, tc[1]);                                   // chunk 1: newer are chunk 0's stores (4) and chunk 2 (4)
+      E_WAIT4(8, tc[1]);                       // chunk 1: newer are chunk 0's stores (4) and chunk 2 (4)
       chunk(std::integral_constant<int, 1>{});
       tload(std::integral_constant<int, 3>{});
-      E_WAIT4(8, tc[0]);                                   // chunk 2: newer are chunk 1's stores and chunk 3
+      E_WAIT4(8, tc[0]);                       // chunk 2: newer are chunk 1's stores and chunk 3
       chunk(std::integral_constant<int, 2>{});
-      E_WAIT4(4, tc[1]);                                   // chunk 3: newer are chunk 2's stores
+      E_WAIT4(4, tc[1]);                       // chunk 3: newer are chunk 2's stores
       chunk(std::integral_constant<int, 3>{});
       // every wave has read the exchange area before any wave's next tile refills the slot (LDS-DMA in phase 1 of its first K-tile)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

@@ -37,7 +37,12 @@ class _VICRegFn(torch.autograd.Function):
         # ix, iy, jx, jy: index lists of the invariance rows (shift masks == 1) and of the statistics rows (image masks == 1)
         # group: a torch.distributed process group -> statistics over the lines of ALL its ranks (see VICRegLoss)
         D = x.shape[-1]
-        x2, y2 = _rows(x, dtype), _rows(y, dtype)
+        stacked = y is None   # x = both views stacked along dim 0 (one tensor, ONE gradient: no slice-backward fill / copy / add kernels)
+        if stacked:
+            xy = _rows(x, dtype)
+            x2, y2 = xy[:xy.shape[0] // 2], xy[xy.shape[0] // 2:]
+        else:
+            x2, y2 = _rows(x, dtype), _rows(y, dtype)
         if ix.numel() != iy.numel():
             raise RuntimeError(f"The size of tensor a ({ix.numel()}) must match the size of tensor b ({iy.numel()}) "
                                "at non-singleton dimension 0")  # what mse_loss reports in the reference
@@ -78,7 +83,7 @@ class _VICRegFn(torch.autograd.Function):
         G, covl = ops.vicreg_cov(cov, cvar, m, wv, wc, dtype)
         loss = wv * var + wi * inv + wc * covl
         ctx.save_for_backward(x2, y2, ix, iy, jx, jy, zc, G)
-        ctx.meta = (x.shape, y.shape, n1, m_loc, wi * 2.0 / (n_inv * D), dtype)
+        ctx.meta = (x.shape, None if stacked else y.shape, n1, m_loc, wi * 2.0 / (n_inv * D), dtype)
         ctx.seed = float(world)
         ctx.mark_non_differentiable(var, inv, covl)
         return loss[0], var[0], inv[0], covl[0]
@@ -91,11 +96,17 @@ class _VICRegFn(torch.autograd.Function):
         # gradient AVERAGE over ranks would divide the sum of those parts by world, so the seed is multiplied by world
         gdev = g.detach().reshape(1).to(torch.float32) * ctx.seed
         dzc = ops.gemm(zc, G)  # (m_pad, D): d(wv*var + wc*cov)/d zc
-        dx = ops.zeros(x2.shape, x2.device, x2.dtype)
-        dy = ops.zeros(y2.shape, y2.device, y2.dtype)
+        if ys is None:   # stacked views: one gradient buffer, the two halves are the views' gradients
+            dxy = ops.zeros((2 * x2.shape[0], x2.shape[1]), x2.device, x2.dtype)
+            dx, dy = dxy[:x2.shape[0]], dxy[x2.shape[0]:]
+        else:
+            dx = ops.zeros(x2.shape, x2.device, x2.dtype)
+            dy = ops.zeros(y2.shape, y2.device, y2.dtype)
         ops.scatter_add_rows_scaled(dzc[:n1], jx, dx, gdev)
         ops.scatter_add_rows_scaled(dzc[n1:m], jy, dy, gdev)
         ops.sqdiff_rows_bwd(x2, ix, y2, iy, dx, dy, gdev, inv_coef)
+        if ys is None:
+            return (dxy.view(xs), None) + (None,) * 11
         return (dx.view(xs), dy.view(ys)) + (None,) * 11
 
 
@@ -129,6 +140,11 @@ class VICRegLoss(torch.nn.Module):
                                               compute_dtype(), self._group())
         return {"loss": loss, "loss.variance": var, "loss.invariance": inv, "loss.covariance": cov}
 
+    def forward_stacked(self, xy, image_masks1, image_masks2, shift_masks1, shift_masks2):
+        """forward(xy[:n], xy[n:], ...) for the two views' head outputs stacked along dim 0 (what the batched 2N-line encode produces): the
+        same values, and ONE gradient tensor for xy - slicing the views apart made autograd fill, copy and add three tensors of xy's size."""
+        return self.forward(xy, None, image_masks1, image_masks2, shift_masks1, shift_masks2)
+
 
     def _group(self):
         if not self.global_statistics:
@@ -141,32 +157,43 @@ class VICRegLoss(torch.nn.Module):
 class _NTXentFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, y, temperature, dtype):
-        n, s, D = x.shape
-        xn, invx = ops.rownorm_fwd(_rows(x, dtype))
-        yn, invy = ops.rownorm_fwd(_rows(y, dtype))
+        stacked = y is None   # x = both views stacked along dim 0: one normalisation launch, ONE gradient tensor
+        if stacked:
+            n, s, D = x.shape[0] // 2, x.shape[1], x.shape[2]
+            xyn, invxy = ops.rownorm_fwd(_rows(x, dtype))
+        else:
+            n, s, D = x.shape
+            # (the two views normalised into the halves of one buffer: the backward then is the stacked one's)
+            xyn = torch.empty((2 * n * s, D), device=x.device, dtype=dtype)
+            invxy = torch.empty(2 * n * s, device=x.device, dtype=torch.float32)
+            ops.rownorm_fwd(_rows(x, dtype), out=(xyn[:n * s], invxy[:n * s]))
+            ops.rownorm_fwd(_rows(y, dtype), out=(xyn[n * s:], invxy[n * s:]))
+        xn, yn = xyn[:n * s], xyn[n * s:]
         sim = torch.empty((n, s, s), device=x.device, dtype=torch.float32)
         ops.gemm_raw(xn, yn, sim, s, s, D, D, D, s, batch=n, sA=(s * D, 0), sB=(s * D, 0), sC=(s * s, 0),
                      alpha=1.0 / temperature)
         loss, _, dsim = ops.ntxent_cols(sim, dtype)
-        ctx.save_for_backward(xn, yn, invx, invy, dsim)
-        ctx.meta = (x.shape, temperature)
+        ctx.save_for_backward(xyn, invxy, dsim)
+        ctx.meta = ((n, s, D), temperature, stacked)
         return loss[0]
 
     @staticmethod
     def backward(ctx, g):
-        xn, yn, invx, invy, dsim = ctx.saved_tensors
-        (n, s, D), temperature = ctx.meta
+        xyn, invxy, dsim = ctx.saved_tensors
+        (n, s, D), temperature, stacked = ctx.meta
+        xn, yn = xyn[:n * s], xyn[n * s:]
         gdev = g.detach().reshape(1).to(torch.float32)
-        dxn = torch.empty_like(xn)
-        dyn = torch.empty_like(yn)
+        dxyn = torch.empty_like(xyn)
+        dxn, dyn = dxyn[:n * s], dxyn[n * s:]
         # d xn = dsim @ yn / T ; d yn = dsim^T @ xn / T   (per line)
         ops.gemm_raw(dsim, yn, dxn, s, D, s, s, D, D, batch=n, sA=(s * s, 0), sB=(s * D, 0), sC=(s * D, 0),
                      alpha=1.0 / temperature, flags=GEMM_TRANS_B)
         ops.gemm_raw(dsim, xn, dyn, s, D, s, s, D, D, batch=n, sA=(s * s, 0), sB=(s * D, 0), sC=(s * D, 0),
                      alpha=1.0 / temperature, flags=GEMM_TRANS_A | GEMM_TRANS_B)
-        dx = ops.rownorm_bwd(xn, dxn, invx, gdev)
-        dy = ops.rownorm_bwd(yn, dyn, invy, gdev)
-        return dx.view(n, s, D), dy.view(n, s, D), None, None
+        dxy = ops.rownorm_bwd(xyn, dxyn, invxy, gdev)     # both views: one launch, one tensor
+        if stacked:
+            return dxy.view(2 * n, s, D), None, None, None
+        return dxy[:n * s].view(n, s, D), dxy[n * s:].view(n, s, D), None, None
 
 
 def _is_nccl(group):
@@ -275,7 +302,14 @@ class NTXentLoss(torch.nn.Module):
                                  "(NT-Xent of the reference is only defined for all-ones masks)")
         if not self.cross_rank_negatives:
             return {"loss": _NTXentFn.apply(x, y, float(self.temperature), compute_dtype())}
+        if y is None:
+            n = x.shape[0] // 2
+            x, y = x[:n], x[n:]
         return {"loss": self._cross(x, y)}
+
+    def forward_stacked(self, xy, image_masks1, image_masks2, shift_masks1, shift_masks2):
+        """forward(xy[:n], xy[n:], ...) for the two views stacked along dim 0: same values, ONE gradient tensor for xy (see VICRegLoss)."""
+        return self.forward(xy, None, image_masks1, image_masks2, shift_masks1, shift_masks2)
 
     def _cross(self, x, y):
         group = None

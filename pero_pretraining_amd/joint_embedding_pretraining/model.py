@@ -74,6 +74,11 @@ class JointEmbeddingTransformerEncoder(torch.nn.Module):
             n = images1.shape[0]
             tokens = self.backbone.encode_tokens_views([images1, images2])
             out = self.head(tokens.view(2 * n, -1, tokens.shape[-1]))
+            if hasattr(self.loss, "forward_stacked"):
+                # the loss reads both views from the ONE tensor the head wrote and returns one gradient for it (slicing them apart made
+                # autograd fill, copy and add three tensors of the output's size per step)
+                loss = self.loss.forward_stacked(out, image_masks1, image_masks2, shift_masks1, shift_masks2)
+                return {"output1": out[:n].detach(), "output2": out[n:].detach(), **loss}
             output1, output2 = out[:n], out[n:]
         else:
             output1 = self.encode(images1)

@@ -165,7 +165,10 @@ class TransformerEncoder(ABC, torch.nn.Module):
         n, seq = views[0].shape[0], views[0].shape[-1 if views[0].dtype != torch.uint8 else 2] // self.patch_size[1]
         drawn = [self.position_model.draw_offsets(n, seq, views[0].device) for _ in views]
         offsets = None if any(o is None for o in drawn) else torch.cat(drawn)
-        x = torch.cat(views, dim=0)
+        # (two device copies into one buffer: torch.cat of the uint8 views is an at::native gather kernel at a third of the copy rate)
+        x = torch.empty((len(views) * n,) + tuple(views[0].shape[1:]), device=views[0].device, dtype=views[0].dtype)
+        for k, v in enumerate(views):
+            x[k * n:(k + 1) * n].copy_(v)
         tokens = _BackboneFn.apply(self, x, None, offsets, compute_dtype(), *self._param_list)
         return tokens  # (len(views) * N * S, model_dim): view v, line i at rows (v * N + i) * S ...
 

@@ -469,10 +469,14 @@ def scatter_add_rows_scaled(src, index, dst, g):
     return dst
 
 
-def rownorm_fwd(x):
+def rownorm_fwd(x, out=None):
     rows, d = x.shape
-    xn = torch.empty_like(x)
-    inv = torch.empty(rows, device=x.device, dtype=torch.float32)
+    if out is not None:
+        xn, inv = out
+        assert xn.shape == x.shape and xn.is_contiguous() and inv.numel() == rows and inv.is_contiguous()
+    else:
+        xn = torch.empty_like(x)
+        inv = torch.empty(rows, device=x.device, dtype=torch.float32)
     call("pero_rownorm_fwd", ptr(x), ptr(xn), ptr(inv), rows, d, dt(x), stream())
     return xn, inv
 

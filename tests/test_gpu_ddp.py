@@ -384,3 +384,32 @@ def test_one_rank_rccl_group_runs_every_collective_path_and_changes_nothing():
     (ld, pd), (lp, pp) = res["step_dp"], res["step_plain"]
     assert abs(ld - lp) <= 1e-6 * abs(lp)
     assert np.abs(pd - pp).max() <= 1e-6
+
+
+def test_bench_two_ranks_rehearsal_emits_the_world_gt_1_legs():
+    """`python bench.py --gpus 2` on THIS box: the self-launch relay starts two ranks that share the one GPU and exchange over gloo
+    (PERO_BENCH_REHEARSE_GLOO=1 - RCCL needs a device per rank), i.e. every world > 1 code path of the bench runs: the data-parallel
+    masked step, config 4 under DataParallel with per-rank and with exact global VICReg statistics, config 5 with cross-rank negatives.
+    The timings mean nothing (two ranks on one device) and the line says so; what is checked is that the ONE JSON line arrives with
+    world_size 2 in the headline and in each of the three legs, finite losses, and n_gpus == 2."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PERO_BENCH_REHEARSE_GLOO="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--repeats", "1", "--batch", "32",
+                        "--leg-pairs", "8,16", "--no-cpu-baseline", "--no-sweep", "--no-options", "--no-roofline"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode(errors="replace")[-3000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout.decode()[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["distributed"]["world_size"] == 2 and "REHEARSAL" in d["distributed"]["backend"] and d["distributed"]["self_launched"]
+    assert d["config"]["global_batch"] == 64 and np.isfinite(d["final_loss"]) and d["value"] > 0
+    want = {"config4_vicreg_dp", "config4_vicreg_dp_global_statistics", "config5_ntxent_dp_cross_rank_negatives"}
+    assert set(d["legs"]) == want, set(d["legs"])
+    for k in want:
+        leg = d["legs"][k]
+        assert leg["distributed"]["world_size"] == 2 and np.isfinite(leg["loss"]) and leg["ms_per_step"] > 0, (k, leg)
