@@ -536,7 +536,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the config 3 / 4 / 5 legs")
     ap.add_argument("--legs-only", action="store_true", help="only the config 3 / 4 / 5 legs (profiling)")
-    ap.add_argument("--leg", default=None, help="with --legs-only: only this leg (config3_vq_argmin, config3_masked_step, config4_vicreg_step, config5_ntxent_step)")
+    ap.add_argument("--leg", default=None, help="with --legs-only: only these legs, comma-separated (config3_vq_argmin, config3_masked_step, config4_vicreg_step, config5_ntxent_step)")
     ap.add_argument("--leg-pairs", default="128,512", help="line pairs per GPU of the config 4 / config 5 legs (the tests' rehearsal shrinks them)")
     ap.add_argument("--no-sweep", action="store_true", help="skip the small-batch sweep and the bandwidth-bound kernel block")
     ap.add_argument("--dp-no-overlap", action="store_true", help="data parallel: reduce all gradients after the backward pass (A/B of the bucket hooks)")
@@ -724,7 +724,7 @@ def main():
         legs = {}
         vp, npairs = (int(v) for v in args.leg_pairs.split(","))
         if world == 1:
-            want = lambda name: args.leg is None or args.leg == name
+            want = lambda name: args.leg is None or name in args.leg.split(",")
             if want("config3_vq_argmin"):
                 legs["config3_vq_argmin"] = leg_config3(timer, device)
             if want("config3_masked_step"):

@@ -363,7 +363,7 @@ def backbone_bwd(mod, saved, dt, dtype, on_layer_done=None):
     if a0.shape[1] == kp:
         linear_bwd(dy0, a0, cw, mod.conv_layer.bias, dtype, need_dx=False, bias_grad_done=True)
     elif cw.requires_grad:  # padded pitch: dW into a (d, pitch) scratch, then add the real columns into .grad
-        tmp = torch.zeros((cw.shape[0], a0.shape[1]), device=a0.device, dtype=torch.float32)
+        tmp = ops.zeros((cw.shape[0], a0.shape[1]), a0.device, torch.float32)
         ops.gemm(dy0, a0, out=tmp, trans_a=True, trans_b=True, atomic=True, k_split=0)
         ops.add_rows2d(ensure_grad(cw).view(cw.shape[0], kp), tmp, kp)
     side.join()

@@ -59,7 +59,7 @@ class _VICRegFn(torch.autograd.Function):
         z = torch.empty((m_pad, D), device=x2.device, dtype=dtype)
         ops.gather_rows(x2, jx, out=z[:n1])
         ops.gather_rows(y2, jy, n_rows_out=m_pad - n1, out=z[n1:])
-        cs = torch.zeros(D, device=x2.device, dtype=torch.float32)
+        cs = ops.zeros((D,), x2.device, torch.float32)
         ops.colsum(z, cs)
         if group is not None:
             # exchange 1: column sums (D floats) -> the GLOBAL mean; pero_center_cols divides by its row count, so the
@@ -71,7 +71,7 @@ class _VICRegFn(torch.autograd.Function):
         # rows centred with the global mean: sum over ranks of zc^T zc IS the global scatter matrix
         if dtype == torch.bfloat16:
             # the D x D SYRK as a split-K product into a zeroed f32 matrix: the long-reduction mode of the 256x256x64 kernel
-            cov = torch.zeros((D, D), device=x2.device, dtype=torch.float32)
+            cov = ops.zeros((D, D), x2.device, torch.float32)   # (64 MiB at D = 4096: the library's linear fill, not torch's elementwise one)
             ops.gemm(zc, zc, out=cov, trans_a=True, trans_b=True, alpha=1.0 / (m - 1), atomic=True, k_split=0)
         else:
             cov = ops.gemm(zc, zc, trans_a=True, trans_b=True, alpha=1.0 / (m - 1), out_dtype=torch.float32)

@@ -13,6 +13,10 @@ class Trainer(_Base):
             output = self.model.forward(images1, images2, image_masks1, image_masks2, shift_masks1, shift_masks2)
         loss = output["loss"]
         if self.data_parallel is not None:
+            # NTXentLoss(cross_rank_negatives=True) applies the upstream gradient once, at the end of its backward - gradients that arrive from
+            # other ranks' negatives are scaled by the LOCAL seed, which is right only if every rank seeds the same scalar (here: 1)
+            if getattr(self.model.loss, "cross_rank_negatives", False) and getattr(self.data_parallel, "loss_weighting", "rank_mean") != "rank_mean":
+                raise ValueError("NTXentLoss(cross_rank_negatives=True) needs the same backward seed on every rank: DataParallel(loss_weighting='rank_mean')")
             self.data_parallel.begin_backward()
         loss.backward()
         if self.data_parallel is not None:

@@ -193,6 +193,17 @@ class MaskedTransformerEncoder(torch.nn.Module):
     # head / loss nodes (result["output"] then stays differentiable).  Needs the mask's row list without a device sync
     # (masked_row_list); otherwise the dense path runs.
     head_backward = "masked"
+    # Debug switch for both row-list modes (costs one device sync per step): the list the step works from - the caller's `rows`, or the one
+    # built from the host twin of an uploaded mask - is compared with the mask ON THE DEVICE; a mask edited in place after its upload, or a
+    # caller's list that misses positions, raises instead of giving a loss over the wrong rows.
+    check_masked_rows = False
+
+    def _check_rows(self, mask, index):
+        m = torch.as_tensor(mask)
+        want = torch.nonzero(m.reshape(-1).to(index.device) == 1, as_tuple=False).reshape(-1)
+        if want.numel() != index.numel() or not torch.equal(want, index.reshape(-1).to(want.dtype)):
+            raise ValueError(f"masked row list ({index.numel()} rows) does not match the mask on the device ({want.numel()} positions with mask == 1): "
+                             "the mask was modified after its upload, or `rows` is not its list of masked positions")
 
     def __init__(self, backbone, head, loss=None):
         super().__init__()
@@ -209,6 +220,8 @@ class MaskedTransformerEncoder(torch.nn.Module):
             return None  # the dense path reproduces the reference's NaN for an empty selection
         tokens = self.backbone.encode_tokens(x, mask)                # (N*S, d)
         index = index.to(tokens.device)
+        if self.check_masked_rows:
+            self._check_rows(mask, index)
         n_pad = ((n + 255) // 256) * 256                              # whole 256-row GEMM tiles; pad rows are zero
         rows = _GatherTokensFn.apply(tokens, index, n_pad)
         logits = self.head(rows)                                      # (n_pad, V)
@@ -237,6 +250,8 @@ class MaskedTransformerEncoder(torch.nn.Module):
                 tokens = self.backbone.encode_tokens(x, mask)
                 if not isinstance(mask, torch.Tensor):
                     mask = torch.from_numpy(np.asarray(mask))
+                if self.check_masked_rows:
+                    self._check_rows(mask, index.to(tokens.device))
                 logits, loss = _HeadCEFn.apply(tokens, self.head.linear.weight, self.head.linear.bias, torch.as_tensor(labels), mask,
                                                index.to(tokens.device, non_blocking=True), compute_dtype())
                 return {"output": logits.view(n, -1, logits.shape[-1]), "loss": loss}

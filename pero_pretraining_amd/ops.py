@@ -441,7 +441,7 @@ def sqdiff_rows_bwd(x, ix, y, iy, dx, dy, g, coef):
 def center_cols(z, colsum_, m):
     m_pad, d = z.shape
     zc = torch.empty_like(z)
-    sumsq = torch.zeros(d, device=z.device, dtype=torch.float32)
+    sumsq = zeros((d,), z.device, torch.float32)
     call("pero_center_cols", ptr(z), ptr(colsum_), ptr(zc), ptr(sumsq), m, m_pad, d, dt(z), stream())
     return zc, sumsq
 

@@ -304,3 +304,36 @@ def test_fused_input_gradient_layernorm_backward(e256, M, K):
         dg2, db2, dxs2 = init.clone(), init.clone(), init.clone()
         again = ops.gemm_resid_layernorm_bwd(dy, wt, res, t, rstd, gamma, beta, dg2, db2, dxs2)
         assert torch.equal(again, dx) and torch.equal(dg2, dg) and torch.equal(db2, db) and torch.equal(dxs2, dxs)
+
+
+def test_fused_linear_residual_layernorm_on_strided_operands(e256):
+    """pero_gemm_resid_layernorm through the C ABI with every leading dimension larger than its row: A and the residual as column slices of
+    wider matrices, Y and T written into column slices of wider buffers - the same bits as the contiguous call, the neighbouring columns
+    untouched (the LayerNorm epilogue's own stores and side loads use ldy / ldr / ldt, the row statistics stay contiguous)."""
+    ops = e256
+    from pero_pretraining_amd import _lib
+    M, K = 1152, 640
+    torch.manual_seed(23)
+    xa = (torch.randn(M, K + 192, device="cuda") * 0.5).bfloat16()
+    wa = (torch.randn(512, K + 64, device="cuda") * 0.05).bfloat16()
+    ra = torch.randn(M, 512 + 256, device="cuda").bfloat16()
+    x, w, res = xa[:, 128:128 + K], wa[:, :K], ra[:, 64:64 + 512]
+    bias = torch.randn(512, device="cuda")
+    gamma = torch.rand(512, device="cuda") + 0.5
+    beta = torch.randn(512, device="cuda") * 0.1
+    y0, t0, m0, r0 = ops.gemm_resid_layernorm(x.contiguous(), w.contiguous(), bias, res.contiguous(), gamma, beta, 1e-5)
+    ya = torch.full((M, 512 + 384), 7.0, device="cuda").bfloat16()
+    ta = torch.full((M, 512 + 128), 7.0, device="cuda").bfloat16()
+    y, t = ya[:, 256:256 + 512], ta[:, 64:64 + 512]
+    mean = torch.empty(M, device="cuda")
+    rstd = torch.empty(M, device="cuda")
+    for store_y in (True, False):
+        ya.fill_(7.0); ta.fill_(7.0)
+        _lib.call("pero_gemm_resid_layernorm", x.data_ptr(), w.data_ptr(), bias.data_ptr(), res.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                  y.data_ptr() if store_y else None, t.data_ptr(), mean.data_ptr(), rstd.data_ptr(), M, 512, K, x.stride(0), w.stride(0),
+                  y.stride(0), res.stride(0), t.stride(0), 1e-5, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert torch.equal(t, t0) and torch.equal(mean, m0) and torch.equal(rstd, r0)
+        assert torch.equal(y, y0) if store_y else bool(torch.all(y == 7.0))
+        assert bool(torch.all(ya[:, :256] == 7.0)) and bool(torch.all(ya[:, 768:] == 7.0))
+        assert bool(torch.all(ta[:, :64] == 7.0)) and bool(torch.all(ta[:, 576:] == 7.0))

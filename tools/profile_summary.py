@@ -57,8 +57,42 @@ def pmc(fetch_csv, write_csv, lines, out):
               open(out, "w"), indent=1)
 
 
+def pmc_legs(base, out):
+    """Per leg (gpurun_out/pmcl_<leg>_<COUNTER>/ of tools/pmc_legs.sh): average HBM bytes per launch of the leg's dominant kernel family -
+    the codebook argmin kernel for config 3, the bf16 tile GEMMs (split-K reduce passes counted into their products) for configs 4 / 5."""
+    import glob, os
+    legs = {}
+    for leg, pat in (("config3_vq_argmin", "vq_argmin"), ("config4_vicreg_step", "gemm_bf16"), ("config5_ntxent_step", "gemm_bf16")):
+        tot = {}
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            files = glob.glob(os.path.join(base, f"pmcl_{leg}_{counter}", "*counter_collection.csv"))
+            if not files:
+                break
+            acc, n, extra = 0.0, 0, 0.0
+            for r in csv.DictReader(open(files[0])):
+                if r.get("Counter_Name") != counter:
+                    continue
+                name = r["Kernel_Name"]
+                if pat in name:
+                    acc += float(r["Counter_Value"]); n += 1
+                elif pat == "gemm_bf16" and name.startswith("pero_splitk_reduce_k"):
+                    extra += float(r["Counter_Value"])
+            tot[counter] = (acc + extra, n)
+        if len(tot) == 2 and tot["FETCH_SIZE"][1]:
+            n = tot["FETCH_SIZE"][1]
+            legs[leg] = {"kernels": pat, "launches": n, "fetch_bytes_per_launch": round(2 * tot["FETCH_SIZE"][0] * 1024 / n),
+                         "write_bytes_per_launch": round(tot["WRITE_SIZE"][0] * 1024 / max(tot["WRITE_SIZE"][1], 1)),
+                         "hbm_bytes_per_launch": round(2 * tot["FETCH_SIZE"][0] * 1024 / n + tot["WRITE_SIZE"][0] * 1024 / max(tot["WRITE_SIZE"][1], 1))}
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    json.dump({"csrc_sha256": bench.csrc_hash(), "legs": legs,
+               "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 correction); separate --pmc passes, one leg per run"}, open(out, "w"), indent=1)
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "stats":
+    if sys.argv[1] == "pmc_legs":
+        pmc_legs(sys.argv[2], sys.argv[3])
+    elif sys.argv[1] == "stats":
         stats(sys.argv[2], int(sys.argv[3]), sys.argv[4])
     else:
         pmc(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5])
