@@ -156,6 +156,19 @@ int pero_layernorm_bwd_out(const void* dy, const void* t, const float* rstd, con
                            void* dx, float* dgamma, float* dbeta, float* dxsum, float* work, int64_t rows, int64_t d,
                            int dtype, void* stream);
 
+/* ---- BatchNorm1d (+ ReLU) over the rows of an (rows, d) matrix: the optional `use_bn=True` layers of the joint-embedding MLPHead
+ * (Linear -> torch.nn.BatchNorm1d(hidden) -> ReLU on the (N*S, hidden) rows: joint_embedding_pretraining/model.py:99-103).
+ * training != 0: batch statistics (mean, BIASED variance; two passes), save_mean / save_rstd (f32 [d]) for the backward, and - when given -
+ * running_mean / running_var updated in place as torch does (momentum; the running variance takes the unbiased batch variance).
+ * training == 0: the running statistics.  y = (x - mean) * rstd * weight + bias, then ReLU if relu != 0.  work: f32 [2 * d].  Deterministic
+ * (no atomics).  Statistics are per CALL, i.e. per data-parallel rank (torch.nn.BatchNorm1d under DDP without SyncBatchNorm). */
+int pero_bn_fwd(const void* x, const float* weight, const float* bias, float* running_mean, float* running_var, void* y,
+                float* save_mean, float* save_rstd, float* work, int64_t rows, int64_t d, float eps, float momentum, int training,
+                int relu, int dtype, void* stream);
+/* dx; dweight / dbias (may be null) ACCUMULATED (+=).  relu != 0: dy is first zeroed where the layer's output y is <= 0.  work: f32 [2 * d]. */
+int pero_bn_bwd(const void* dy, const void* x, const void* y, const float* weight, const float* save_mean, const float* save_rstd,
+                void* dx, float* dweight, float* dbias, float* work, int64_t rows, int64_t d, int relu, int dtype, void* stream);
+
 /* ---- softmax over the last dim (attention probabilities; torch SDPA inside
  * TransformerEncoderLayer._sa_block, models/transformers.py:86) ---------------------------------------
  * p = softmax(scale * s) row-wise; s is f32 (rows, cols), p has `dtype` */

@@ -301,6 +301,38 @@ def vicreg_loss(x, y, image_masks1, image_masks2, shift_masks1, shift_masks2,
             "loss.covariance": covariance}
 
 
+def mlp_head(x, sd, use_bn=False, training=True, momentum=0.1, eps=1e-5):
+    """joint_embedding_pretraining/model.py:79-115 restated: MLPHead on (N, S, D) -> Linear [BatchNorm1d] ReLU ... Linear over the (N*S, D)
+    rows.  sd: the head's state dict (`layers.{i}.*`, torch tensors).  BatchNorm1d (torch.nn.BatchNorm1d semantics, model.py:99-100): in
+    training the batch mean and BIASED variance normalise, the running statistics move by `momentum` towards the batch mean and the
+    UNBIASED batch variance; in evaluation the running statistics normalise.  Returns (y (N, S, hidden), {buffer name: new value})."""
+    n, s_, d = x.shape
+    y = x.reshape(n * s_, d)
+    idx = sorted({int(k.split(".")[1]) for k in sd if k.startswith("layers.")})
+    lin = [i for i in idx if sd[f"layers.{i}.weight"].dim() == 2]
+    new_buffers = {}
+    for j, i in enumerate(lin):
+        y = y @ sd[f"layers.{i}.weight"].t() + sd[f"layers.{i}.bias"]
+        if j == len(lin) - 1:
+            break
+        if use_bn:
+            b = i + 1
+            if training:
+                m = y.shape[0]
+                mean = y.sum(dim=0) / m
+                cen = y - mean
+                var = (cen * cen).sum(dim=0) / m
+                new_buffers[f"layers.{b}.running_mean"] = (1 - momentum) * sd[f"layers.{b}.running_mean"] + momentum * mean.detach()
+                new_buffers[f"layers.{b}.running_var"] = (1 - momentum) * sd[f"layers.{b}.running_var"] + momentum * (var.detach() * m / (m - 1))
+                new_buffers[f"layers.{b}.num_batches_tracked"] = sd[f"layers.{b}.num_batches_tracked"] + 1
+            else:
+                mean, var = sd[f"layers.{b}.running_mean"], sd[f"layers.{b}.running_var"]
+                cen = y - mean
+            y = cen / torch.sqrt(var + eps) * sd[f"layers.{b}.weight"] + sd[f"layers.{b}.bias"]
+        y = torch.clamp_min(y, 0.0)
+    return y.reshape(n, s_, -1), new_buffers
+
+
 def ntxent_loss(x, y, image_masks1, image_masks2, shift_masks1, shift_masks2, temperature=0.1):
     """joint_embedding_pretraining/losses.py:56-83.  Per line: rows selected by shift masks, cosine
     similarities / T, softmax normalised over dim 0 (columns), -log of the diagonal, mean.

@@ -69,6 +69,8 @@ SIGNATURES = {
     "pero_rowdot_blocks": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp],
     "pero_gemm_resid_layernorm": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f32, _vp],
     "pero_gemm_resid_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _vp],
+    "pero_bn_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _f32, _f32, _i32, _i32, _i32, _vp],
+    "pero_bn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp],
     "pero_label_rank": [_vp, _i64, _vp, _vp, _i64, _i64, _vp, _i32, _vp, _vp, _i32, _vp],
     "pero_stack_lines": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp],
     "pero_line_masks": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp],

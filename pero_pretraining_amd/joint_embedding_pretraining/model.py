@@ -2,9 +2,12 @@
 JointEmbeddingTransformerEncoder, LinearHead, MLPHead."""
 import torch
 
+from .. import functional as F
+from .. import ops
 from ..masked_pretraining.model import LinearHead as _LinearHead
 from ..masked_pretraining.model import linear
 from ..models.transformers import VisionTransformerEncoder
+from ..precision import compute_dtype
 
 
 def init_backbone(backbone_definition):
@@ -33,28 +36,77 @@ class LinearHead(_LinearHead):
     pass
 
 
+class _BatchNormReluFn(torch.autograd.Function):
+    """torch.nn.BatchNorm1d followed by ReLU on (rows, d) rows as one node on pero_bn_fwd / pero_bn_bwd (csrc/bnorm.hip): batch statistics in
+    training (running statistics updated in place, momentum and the unbiased running variance as torch does), running statistics in eval."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, bn, dtype):
+        x2 = x.detach()
+        if x2.dtype != dtype or not x2.is_contiguous():
+            x2 = x2.to(dtype).contiguous()
+        training = bn.training or bn.running_mean is None
+        momentum = 0.1 if bn.momentum is None else bn.momentum
+        if training and bn.track_running_stats and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
+            if bn.momentum is None:   # torch: cumulative moving average
+                momentum = 1.0 / float(bn.num_batches_tracked)
+        y, mean, rstd = ops.bn_fwd(x2, weight.detach(), bias.detach(), bn.running_mean if bn.track_running_stats else None,
+                                   bn.running_var if bn.track_running_stats else None, bn.eps, momentum, training, True)
+        ctx.save_for_backward(x2, y, mean, rstd)
+        ctx.weight, ctx.bias, ctx.training = weight, bias, training
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, y, mean, rstd = ctx.saved_tensors
+        g = dy.detach()
+        if g.dtype != x2.dtype or not g.is_contiguous():
+            g = g.to(x2.dtype).contiguous()
+        if not ctx.training:
+            raise RuntimeError("BatchNorm backward in evaluation mode is not implemented (training-mode statistics only)")
+        dw = F.ensure_grad(ctx.weight) if ctx.weight.requires_grad else None
+        db = F.ensure_grad(ctx.bias) if ctx.bias.requires_grad else None
+        dx = ops.bn_bwd(g, x2, y, ctx.weight.detach(), mean, rstd, dw, db, True)
+        return dx, None, None, None, None
+
+
 class MLPHead(torch.nn.Module):
-    """Linear(in,h) ReLU [Linear(h,h) ReLU]* Linear(h,h); parameters under `layers.{i}` exactly as the reference's
-    torch.nn.Sequential (joint_embedding_pretraining/model.py:79-115).  ReLUs are fused into the GEMM epilogues."""
+    """Linear(in,h) [BatchNorm1d(h)] ReLU [Linear(h,h) [BatchNorm1d(h)] ReLU]* Linear(h,h); parameters and buffers under `layers.{i}` exactly as
+    the reference's torch.nn.Sequential (joint_embedding_pretraining/model.py:79-115).  Without BatchNorm the ReLUs are fused into the GEMM
+    epilogues; with `use_bn=True` (round 4; reference default False) BatchNorm + ReLU run as one HIP node between the products.  BatchNorm
+    statistics are those of the rows THIS process sees: under data-parallel training they are per rank, exactly like torch.nn.BatchNorm1d
+    under DistributedDataParallel without SyncBatchNorm (gradients are still averaged; the running statistics differ slightly between ranks)."""
 
     def __init__(self, in_dim=512, hidden_dim=8192, num_layers=3, use_bn=False):
         super().__init__()
-        if use_bn:
-            raise NotImplementedError("MLPHead(use_bn=True) is not implemented in the HIP path (reference default: False)")
         self.in_dim, self.hidden_dim, self.num_layers, self.use_bn = in_dim, hidden_dim, num_layers, use_bn
         layers, d = [], in_dim
         for _ in range(num_layers - 1):
-            layers += [torch.nn.Linear(d, hidden_dim), torch.nn.ReLU()]
+            layers.append(torch.nn.Linear(d, hidden_dim))
             d = hidden_dim
+            if use_bn:
+                layers.append(torch.nn.BatchNorm1d(hidden_dim))
+            layers.append(torch.nn.ReLU())
         layers.append(torch.nn.Linear(d, hidden_dim))
         self.layers = torch.nn.Sequential(*layers)
 
     def forward(self, x):
         N, S, D = x.shape
         y = x.reshape(N * S, D)
-        lin = [m for m in self.layers if isinstance(m, torch.nn.Linear)]
+        mods = list(self.layers)
+        lin = [m for m in mods if isinstance(m, torch.nn.Linear)]
+        if not self.use_bn:
+            for i, m in enumerate(lin):
+                y = linear(y, m.weight, m.bias, relu_out=i < len(lin) - 1, gate_in=i > 0)
+            return y.reshape(N, S, -1)
+        if not y.is_cuda:
+            raise RuntimeError("pero_pretraining_amd layers run on the GPU only (HIP kernels, no CPU fallback)")
+        bns = [m for m in mods if isinstance(m, torch.nn.BatchNorm1d)]
         for i, m in enumerate(lin):
-            y = linear(y, m.weight, m.bias, relu_out=i < len(lin) - 1, gate_in=i > 0)
+            y = linear(y, m.weight, m.bias)
+            if i < len(lin) - 1:
+                y = _BatchNormReluFn.apply(y, bns[i].weight, bns[i].bias, bns[i], compute_dtype())
         return y.reshape(N, S, -1)
 
 

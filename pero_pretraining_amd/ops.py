@@ -204,6 +204,28 @@ def layernorm_bwd_out(dy, t, rstd, gamma, beta, dgamma, dbeta, dxsum=None):
     return dx
 
 
+def bn_fwd(x, weight, bias, running_mean, running_var, eps, momentum, training, relu):
+    """BatchNorm1d (+ ReLU) over the rows of x (rows, d): returns (y, save_mean, save_rstd); running statistics updated in place in training."""
+    _req_cuda(x)
+    rows, d = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty(d, device=x.device, dtype=torch.float32)
+    rstd = torch.empty(d, device=x.device, dtype=torch.float32)
+    work = torch.empty(2 * d, device=x.device, dtype=torch.float32)
+    call("pero_bn_fwd", ptr(x), ptr(weight), ptr(bias), ptr(running_mean), ptr(running_var), ptr(y), ptr(mean), ptr(rstd), ptr(work),
+         rows, d, float(eps), float(momentum), int(bool(training)), int(bool(relu)), dt(x), stream())
+    return y, mean, rstd
+
+
+def bn_bwd(dy, x, y, weight, mean, rstd, dweight, dbias, relu):
+    rows, d = x.shape
+    dx = torch.empty_like(x)
+    work = torch.empty(2 * d, device=x.device, dtype=torch.float32)
+    call("pero_bn_bwd", ptr(dy), ptr(x), ptr(y), ptr(weight), ptr(mean), ptr(rstd), ptr(dx), ptr(dweight), ptr(dbias), ptr(work),
+         rows, d, int(bool(relu)), dt(x), stream())
+    return dx
+
+
 def softmax_fwd(scores, scale, out_dtype):
     rows, cols = scores.numel() // scores.shape[-1], scores.shape[-1]
     p = torch.empty(scores.shape, device=scores.device, dtype=out_dtype)

@@ -71,6 +71,29 @@ def test_oracle_mlp_head(golden):
         assert np.abs(ws[i].grad.numpy() - g[f"grad.layers.{k}.weight"]).max() < 1e-4
 
 
+def test_oracle_mlp_head_with_batchnorm(golden):
+    """oracle.mlp_head(use_bn=True) against the reference's own MLPHead(use_bn=True) (g21: two training steps - the second starts from the
+    first one's running statistics - and an evaluation pass): outputs, every gradient, the BatchNorm buffers."""
+    g = golden("g21_mlp_head_bn.npz")
+    sd = {k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd0.")}
+    for step in range(2):
+        x = torch.from_numpy(g[f"s{step}.x"]).requires_grad_(True)
+        prm = {k: (v.clone().requires_grad_(True) if v.dtype == torch.float32 and "running" not in k else v) for k, v in sd.items()}
+        y, bufs = O.mlp_head(x, prm, use_bn=True, training=True)
+        assert np.abs(y.detach().numpy() - g[f"s{step}.y"]).max() < 2e-5
+        (y * torch.from_numpy(g[f"s{step}.gy"])).sum().backward()
+        assert np.abs(x.grad.numpy() - g[f"s{step}.grad_x"]).max() < 1e-4 * max(1.0, np.abs(g[f"s{step}.grad_x"]).max())
+        for k, v in prm.items():
+            if v.requires_grad:
+                ref = g[f"s{step}.grad.{k}"]
+                assert np.abs(v.grad.numpy() - ref).max() < 1e-4 * max(1.0, np.abs(ref).max()), k
+        for k, v in bufs.items():
+            assert np.abs(v.numpy().astype(np.float64) - g[f"s{step}.buf.{k}"]).max() < 1e-5, k
+            sd[k] = v.detach()
+    ye, _ = O.mlp_head(torch.from_numpy(g["eval.x"]), sd, use_bn=True, training=False)
+    assert np.abs(ye.numpy() - g["eval.y"]).max() < 2e-5
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 def cu(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
@@ -120,6 +143,45 @@ def test_mlp_head_matches_reference_golden(golden):
     for k, p in head.named_parameters():
         ref = g["grad." + k]
         assert np.abs(p.grad.cpu().numpy() - ref).max() < 1e-4 * max(1.0, np.abs(ref).max()), k
+
+
+@pytest.mark.gpu
+def test_mlp_head_with_batchnorm_matches_reference_golden(golden):
+    """MLPHead(use_bn=True) on the HIP kernels (pero_bn_fwd / pero_bn_bwd between the products) against the reference's own head (g21), f32
+    parity mode: two training steps (outputs, input gradient, every parameter gradient, running statistics and the batch counter after each),
+    then the evaluation-mode output from the accumulated running statistics; state_dict keys as the reference's."""
+    from pero_pretraining_amd.joint_embedding_pretraining.model import init_head
+    g = golden("g21_mlp_head_bn.npz")
+    head = init_head({"type": "mlp", "in_dim": 48, "hidden_dim": 96, "num_layers": 3, "use_bn": True})
+    assert sorted(head.state_dict()) == sorted(k[4:] for k in g.files if k.startswith("sd0."))
+    head.load_state_dict({k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd0.")})
+    head = head.cuda().train()
+    for step in range(2):
+        head.zero_grad()
+        x = cu(g[f"s{step}.x"]).requires_grad_(True)
+        y = head(x)
+        assert np.abs(y.detach().cpu().numpy() - g[f"s{step}.y"]).max() < 1e-4
+        (y * cu(g[f"s{step}.gy"])).sum().backward()
+        ref = g[f"s{step}.grad_x"]
+        assert np.abs(x.grad.cpu().numpy() - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
+        for k, p in head.named_parameters():
+            ref = g[f"s{step}.grad.{k}"]
+            assert np.abs(p.grad.cpu().numpy() - ref).max() < 1e-4 * max(1.0, np.abs(ref).max()), (step, k)
+        for k, b in head.named_buffers():
+            assert np.abs(b.cpu().numpy().astype(np.float64) - g[f"s{step}.buf.{k}"]).max() < 1e-5, (step, k)
+    head.eval()
+    with torch.no_grad():
+        ye = head(cu(g["eval.x"]))
+    assert np.abs(ye.cpu().numpy() - g["eval.y"]).max() < 1e-4
+    # bf16 mode: the same step within bf16 rounding of the f32 one
+    import pero_pretraining_amd as P
+    head.train()
+    x = cu(g["s0.x"])
+    with torch.no_grad():
+        y32 = head(x)
+        with P.autocast(True):
+            y16 = head(x)
+    assert float((y16.float() - y32).abs().max()) <= 3e-2 * float(y32.abs().max())
 
 
 @pytest.mark.gpu
