@@ -268,7 +268,9 @@ def gemm_roofline(per, nsteps, step_seconds, traffic):
     return {"bound": "mfma",
             "kernel": "bf16 MFMA tile GEMM gemm_bf16_e256 (eight-phase persistent 256x256x64: forward, input gradients with fused "
                       "epilogues, split-K weight gradients) + its row-complete 128x512 form gemm_bf16_n512 (out-projection / linear2 with the "
-                      "residual LayerNorm in the epilogue: the product's flops over the whole launch)",
+                      "residual LayerNorm in the epilogue, linear1's / in_proj's input gradients with the LayerNorm BACKWARD in the epilogue: "
+                      "by_layout tags *_ln_fwd / *_ln_bwd; the product's flops over the WHOLE launch, LayerNorm work and the column-sum reduce "
+                      "included - since round 4 the family carries 47 of the step's 49 LayerNorm passes)",
             "achieved": round(ach, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4),
             "traffic": traffic, "launches_per_step": nl // nsteps, "avg_launch_us": round(tsum / nl * 1e6, 2),
             "gflop_per_launch": round(fsum / nl / 1e9, 3),

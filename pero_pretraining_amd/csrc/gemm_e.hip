@@ -1421,7 +1421,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_n512(GemmP p, LnP q) {
 #pragma unroll
             for (int i = 0; i < 4; i++) {
               const float w = quad(part[ha][i]);
-              if (ep == 0) mine[which * 128 + 64 * ha + 16 * i + er] = w;
+              if (ep == 0) mine[which * 128 + 64 * ha + 16 * i + er + 4 * wave] = w;   // (+ 4 floats per wave: see the read below)
             }
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           N_BAR();
@@ -1429,8 +1429,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_n512(GemmP p, LnP q) {
           for (int ha = 0; ha < 2; ha++)
 #pragma unroll
             for (int i = 0; i < 4; i++) {
+              // wave w's partials sit 4 w floats into its 2 KiB block: the four waves 2 ep a half wave reads from then fall on four different
+              // groups of 8 banks (at the bare 512-float pitch all of them hit the same 8: 4-way conflicts, 6.3 M conflict cycles per launch)
               const int r = which * 128 + 64 * ha + 16 * i + er;
-              part[ha][i] = quad(all[(2 * ep) * 512 + r] + all[(2 * ep + 1) * 512 + r]);
+              part[ha][i] = quad(all[(2 * ep) * 512 + r + 8 * ep] + all[(2 * ep + 1) * 512 + r + 8 * ep + 4]);
             }
         };
         if (!(N_DBG & 8)) exchange(rsum, 0);

@@ -155,7 +155,7 @@ def gemm_resid_layernorm(a, w, bias, residual, gamma, beta, eps, store_y=True):
          M, 512, K, a.stride(0), w.stride(0), y.stride(0) if y is not None else 0, residual.stride(0), t.stride(0), float(eps), stream())
     if gemm_timeline is not None:   # counted with the tile GEMMs of bench.py's roofline: the product's flops over the WHOLE launch (LayerNorm included)
         e1.record()
-        gemm_timeline.append((e0, e1, 2.0 * M * 512 * K, "gemm_bf16_tile:NN"))
+        gemm_timeline.append((e0, e1, 2.0 * M * 512 * K, "gemm_bf16_tile_ln_fwd:NN"))
     return y, t, mean, rstd
 
 
@@ -181,7 +181,7 @@ def gemm_resid_layernorm_bwd(a, w_t, residual, t, rstd, gamma, beta, dgamma, dbe
          ptr(dxsum), ptr(work), M, 512, K, a.stride(0), w_t.stride(0), residual.stride(0), t.stride(0), dx.stride(0), stream())
     if gemm_timeline is not None:   # the product's flops over the WHOLE launch (LayerNorm backward and the reduce included)
         e1.record()
-        gemm_timeline.append((e0, e1, 2.0 * M * 512 * K, "gemm_bf16_tile:NN"))
+        gemm_timeline.append((e0, e1, 2.0 * M * 512 * K, "gemm_bf16_tile_ln_bwd:NN"))
     return dx
 
 

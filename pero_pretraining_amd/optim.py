@@ -36,8 +36,8 @@ class FusedAdam(torch.optim.Optimizer):
             for p in ps:
                 offs.append(total)
                 total += ((p.numel() + 7) // 8) * 8  # 16-byte aligned bf16 views
-            fp = torch.zeros(total, device=dev, dtype=torch.float32)
-            fg = torch.zeros(total, device=dev, dtype=torch.float32)
+            fp = ops.zeros((total,), dev, torch.float32)   # (the library's linear fill: torch's elementwise one runs at a third of its rate)
+            fg = ops.zeros((total,), dev, torch.float32)
             flp = torch.empty(total, device=dev, dtype=torch.bfloat16)
             for p, o in zip(ps, offs):
                 n = p.numel()
@@ -53,13 +53,13 @@ class FusedAdam(torch.optim.Optimizer):
             mats = [(o, o, p.shape[0], p.numel() // p.shape[0]) for p, o in zip(ps, offs) if p.dim() >= 2]
             flpt, ttable, ttiles = None, None, 0
             if mats:
-                flpt = torch.zeros(total, device=dev, dtype=torch.bfloat16)
+                flpt = ops.zeros((total,), dev, torch.bfloat16)
                 ttable, ttiles = ops.transpose_table(mats, dev)
                 ops.transpose_multi(flp, flpt, ttable, ttiles)
                 for p, o in zip(ps, offs):
                     if p.dim() >= 2:
                         lowp.put_t(p, flpt[o:o + p.numel()].view(p.numel() // p.shape[0], p.shape[0]))
-            self._flat.append(dict(p=fp, g=fg, m=torch.zeros_like(fp), v=torch.zeros_like(fp), lp=flp, step=0,
+            self._flat.append(dict(p=fp, g=fg, m=ops.zeros((total,), dev, torch.float32), v=ops.zeros((total,), dev, torch.float32), lp=flp, step=0,
                                    params=ps, offsets=offs, lpt=flpt, ttable=ttable, ttiles=ttiles))
 
     def refresh_lowp(self):
