@@ -31,6 +31,24 @@ def _nz(mask, device, value=1):
     return torch.nonzero(torch.as_tensor(mask).to(device).reshape(-1) == value, as_tuple=False).reshape(-1).contiguous()
 
 
+_host_groups = {}
+
+
+def _host_count_sum(group, *counts):
+    """Sums of a few HOST integers over the ranks of `group` without touching the GPU queue: the counts are all-reduced as a CPU tensor over
+    a gloo companion group of the same ranks (created once per group; a gloo group serves itself).  Round 3 all-reduced them on the device
+    and read them back with .tolist(): one device sync per step in the global-statistics VICReg."""
+    t = torch.tensor(list(counts), dtype=torch.int64)
+    g = group
+    if dist.get_backend(group) != "gloo":
+        key = id(group)
+        if key not in _host_groups:
+            _host_groups[key] = dist.new_group(ranks=dist.get_process_group_ranks(group), backend="gloo")
+        g = _host_groups[key]
+    dist.all_reduce(t, group=g)
+    return tuple(int(v) for v in t.tolist())
+
+
 class _VICRegFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, y, ix, iy, jx, jy, wv, wi, wc, thr, eps, dtype, group=None):
@@ -50,10 +68,8 @@ class _VICRegFn(torch.autograd.Function):
         n1, m_loc = jx.numel(), jx.numel() + jy.numel()
         m, world = m_loc, 1
         if group is not None:  # row counts of the whole batch (exact integers: int64 sum)
-            counts = torch.tensor([n_inv, m_loc], device=x2.device, dtype=torch.int64)
-            dist.all_reduce(counts, group=group)
-            n_inv, m = (int(v) for v in counts.tolist())
             world = dist.get_world_size(group)
+            n_inv, m = _host_count_sum(group, n_inv, m_loc)
         inv = ops.sqdiff_rows(x2, ix, y2, iy, 1.0 / (n_inv * D))
         m_pad = ((m_loc + 63) // 64) * 64
         z = torch.empty((m_pad, D), device=x2.device, dtype=dtype)
