@@ -25,6 +25,9 @@
 // Timing-only ablation builds of the backward kernels (tools/attn_ablate.sh; -DAT_ABL=mask, results wrong by design):
 //   1 no LDS-DMA inside the loops (the prologue's tiles are reused), 2 no exponentials, 4 no gradient MFMAs (dQ / dK / dV products),
 //   8 no output tiles (attn_store_tile), 16 no score MFMAs (S / dP), 32 output tiles staged but not stored, 64 no column sums (bias gradient)
+#ifndef AT_COLSUM_MFMA
+#define AT_COLSUM_MFMA 1   // column sums of the backward's output tiles by MFMA (0: round 3's vector-ALU sums + LDS reduction)
+#endif
 #ifndef AT_ABL
 #define AT_ABL 0
 #endif
@@ -436,6 +439,40 @@ __device__ __forceinline__ void attn_store_tile(const f16v (&acc)[4], unsigned c
       *(uint2*)(stg + row_w * 256 + ((g ^ (row_w & 31)) << 3)) = w;
     }
   __syncthreads();
+#if AT_COLSUM_MFMA
+  const int ch = tid & 15;
+#pragma unroll 2
+  for (int i = 0; i < 8; i++) {
+    const int row = (tid >> 4) + 16 * i;
+    const int x = row & 31;
+    uint4 v = *(const uint4*)(stg + row * 256 + ((ch ^ (x >> 1)) << 4));
+    if (x & 1) { const unsigned t0 = v.x, t1 = v.y; v.x = v.z; v.y = v.w; v.z = t0; v.w = t1; }
+    if (!(AT_ABL & 32)) *(uint4*)(out_base + (long long)row * ld + ch * 8) = v;
+    else if (v.x == 0x12345678u) out_base[0] = 1;   // timing-only build: the staged values stay live, nothing is stored
+  }
+  if (colsum && !(AT_ABL & 64)) {
+    // Column sums of the staged tile (this (line, head) block's share of in_proj's bias gradient) on the MATRIX pipe, which idles through
+    // the epilogue (round 4; lh_store_matrix's trick): wave w takes the 32 columns 32 w .., ones (32 x 16) times the 16 x 32 block of the
+    // image read back TRANSPOSED (ds_read_b64_tr_b16: the row index becomes the MFMA's k - any order of the rows inside a k-step gives the
+    // same sum), accumulated over the eight row blocks: every lane n then holds the sum of column 32 w + (n & 31), exact in f32, and writes
+    // it - no cross-lane shuffles, no second pass through LDS, no barriers.  (As 128 vector adds + 16 shuffles per thread + an LDS
+    // reduction over the four waves behind two barriers the sums were 7 % of the backward: tools/attn_ablate.py, mask 64.)
+    const int lane = tid & 63;
+    const int ti = lane & 15, tg = (lane >> 4) & 1;
+    const int g = 8 * wave + 4 * tg + (ti & 3);                 // 8-byte granule (4 columns) this lane supplies
+    const int q0 = 8 * h5 + (ti >> 2);                          // row inside a 16-row block; the second read takes row + 4
+    const __bf16 one = (__bf16)1.0f;
+    const bf8v ones = {one, one, one, one, one, one, one, one};
+    f16v cs = {0};
+#pragma unroll
+    for (int ks = 0; ks < 8; ks++) {
+      const int ra = 16 * ks + q0, rb = ra + 4;
+      const bf8v frag = lds_tr16_pair(stg + ra * 256 + ((g ^ (ra & 31)) << 3), stg + rb * 256 + ((g ^ (rb & 31)) << 3));
+      cs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, frag, cs, 0, 0, 0);
+    }
+    if (lane < 32) colsum[32 * wave + lane] = cs[0];
+  }
+#else   // round 3: vector-ALU column sums (kept for the A/B: -DAT_COLSUM_MFMA=0)
   const int ch = tid & 15;
   float cs[8];  // column sums of this thread's 8 columns (chunk ch) over its 8 rows, taken from the values on their way out
 #pragma unroll
@@ -472,6 +509,7 @@ __device__ __forceinline__ void attn_store_tile(const f16v (&acc)[4], unsigned c
     __syncthreads();
     if (tid < 128) colsum[tid] = (red[tid] + red[128 + tid]) + (red[256 + tid] + red[384 + tid]);
   }
+#endif
 }
 
 // dbias[which * d + head * 128 + c] += sum over the workgroups (line, block) of partial[which][(lh, blk)][c], lh = line * nh + head.
