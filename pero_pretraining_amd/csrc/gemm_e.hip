@@ -847,6 +847,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p, int ks) {
 #ifndef N_DBG
 #define N_DBG 0   // bring-up switches of the LayerNorm epilogue: 1 no gamma / beta loads (gamma = 1, beta = 0), 2 no mean / rstd stores, 4 pass 2 recomputes nothing (stores y again)
 #endif
+#ifndef LNB_ABL
+#define LNB_ABL 0   // timing-only ablation builds of the LayerNorm-backward epilogue (results wrong by design; tools/lnb_ab.py): 1 no column-sum
+#endif             // butterflies, 2 no pass 1b arithmetic, 4 no pass 2 arithmetic (the packed dt rows are stored), 8 pass 2 without its second load of the t rows
 #define N_BM 128
 #define N_ASLOTS 3
 #define N_BSLOTS 6
@@ -871,7 +874,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_n512(GemmP p, LnP q) {
   constexpr int LNX = LN ? 8 + 2 + 16 : 0;                // LayerNorm: gamma / beta loads, mean / rstd stores, the 16 stores of t
   // vector-memory operations of an epilogue behind its phase-4 side loads.  LayerNorm backward: residual rows 64-127 (8), t rows 0-63 (8), gamma, beta,
   // rstd, t rows 64-127 (4 + 4 + 8 + 8), the rows of t again for pass 2 (16), the 16 stores of dx
-  constexpr int EPO = LNB ? (8 + 8 + 24 + 16 + 16) : (L1 + 2 * SH + LNX);
+  constexpr int EPO = LNB ? (8 + 8 + 8 + 8 + 16 + 16) : (L1 + 2 * SH + LNX);
   constexpr int cap63 = 63;                               // s_waitcnt vmcnt takes six bits: a larger count only asks for more than needed
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1070,11 +1073,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_n512(GemmP p, LnP q) {
       //   pass 1a  accumulators + residual rows -> dt through the lane transpose, rounded and PACKED (the accumulators die here)
       //   pass 1b  the two row sums of the lane's 16 columns, all eight rows;  partials of the eight waves -> the A slot this tile's last K-tile has
       //            left free (the next tile's third K-tile refills it), ONE barrier
-      //   pass 2   four chunks (32-column block hb, row half ha) of four rows: the rows of t come a SECOND time (from the L2 now: kept in registers
-      //            beside the packed dt, the constants and the column sums they spilled 160 registers), per row the totals from the exchange area,
-      //            dx stored; per block the column sums, reduced over the wave's 16 row indices at once.
-      // Vector-memory order (per lane): [phase 4 of the last K-tile: residual rows 0-63 x8] | residual rows 64-127 x8 (halfway through pass 1a of rows 0-63) | t rows 0-63 x8 | gamma x4,
-      // beta x4, rstd x8, t rows 64-127 x8 | t chunks 0, 1 (4 + 4) | 4 stores | t chunk 2 | 4 stores | t chunk 3 | 4 + 4 stores.
+      //   pass 2   four chunks (32-column block hb, row half ha) of four rows: per row the totals from the exchange area, dx stored; per block the
+      //            column sums, reduced over the wave's 16 row indices at once.
+      // Vector-memory order (per lane): [phase 4 of the last K-tile: residual rows 0-63 x8] | t rows 0-63 x8 | residual rows 64-127 x8 (halfway through pass 1a of rows
+      // 0-63) | gamma x4, beta x4 (in the last quarter of pass 1a) | t rows 64-127 x8 | rstd of chunks 0, 1, 2 (4 each) | 4 stores | rstd of chunk 3 | 4 + 4 + 4 stores.
       int lane_e = lane;
       asm volatile("" : "+v"(lane_e));
       const int li_e = lane_e & 15, lq_e = lane_e >> 4;
@@ -1094,11 +1096,17 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_n512(GemmP p, LnP q) {
       };
       auto lo2 = [](unsigned w) -> ef2v { return (ef2v){__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)}; };
       eu4v dtp[2][4][2];
+      // gamma / beta of the lane's 16 columns ([2 hb + half]), rstd of its eight rows
+      const ei4v grs = ersrc(q.gamma + 256 * wr + 64 * wc, 64 * 4), ers = ersrc(q.beta + 256 * wr + 64 * wc, 64 * 4);
+      const ei4v rrs = ersrc(q.rstd + tm0, 128 * 4);
+      const unsigned gvoff = (unsigned)(8 * ep * 4), rvo = (unsigned)(er * 4);
+      eu4v cg[4], cb[4];
       auto pass1a = [&](auto ha_c) __attribute__((always_inline)) {
         constexpr int ha = decltype(ha_c)::value;
         auto& side1_ = side1;   // (hipcc does not capture a variable that a generic lambda names only as an asm operand)
-        const unsigned gvo_ = gvo;
-        const ei4v srs_ = srs;
+        auto& cg_ = cg; auto& cb_ = cb;
+        const unsigned gvo_ = gvo, gvoff_ = gvoff;
+        const ei4v srs_ = srs, grs_ = grs, ers_ = ers;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
           if (ha == 0 && i == 2) {
@@ -1110,6 +1118,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_n512(GemmP p, LnP q) {
               E_BLOAD16(side1_[2 * i2], gvo_, srs_, so, 0);
               E_BLOAD16(side1_[2 * i2 + 1], gvo_, srs_, so, 64);
             }
+          }
+          if (ha == 1 && i == 3) {
+            // the constants go out when three quarters of the accumulators are packed (40 registers; pass 1b needs them first thing)
+            E_BLOAD16(cg_[0], gvoff_, grs_, 0, 0); E_BLOAD16(cg_[1], gvoff_, grs_, 0, 16); E_BLOAD16(cg_[2], gvoff_, grs_, 0, 128); E_BLOAD16(cg_[3], gvoff_, grs_, 0, 144);
+            E_BLOAD16(cb_[0], gvoff_, ers_, 0, 0); E_BLOAD16(cb_[1], gvoff_, ers_, 0, 16); E_BLOAD16(cb_[2], gvoff_, ers_, 0, 128); E_BLOAD16(cb_[3], gvoff_, ers_, 0, 144);
           }
 #pragma unroll
           for (int hb = 0; hb < 2; hb++) {
@@ -1132,37 +1145,29 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_n512(GemmP p, LnP q) {
           __builtin_amdgcn_sched_barrier(0);
         }
       };
-      E_WAIT8(4, side0);   // residual rows 0-63 (phase 4 of the last K-tile): newer are B00 / B10 (4)
-      pass1a(std::integral_constant<int, 0>{});
+      // t rows 0-63 first (they are needed after BOTH halves of pass 1a: issued behind rows 0-63 they had one half to arrive and the wave waited
+      // for HBM; with every arithmetic instruction of this epilogue compiled out it still cost 128 us per launch over the plain residual
+      // epilogue - tools/lnb_ab.py, LNB_ABL = 7: its loads' latency, not its 1 900 vector-ALU instructions, is what the epilogue costs)
 #pragma unroll
-      for (int i = 0; i < 4; i++) {   // t rows 0-63
+      for (int i = 0; i < 4; i++) {
         const int so = 16 * i * tpitch_l;
         E_BLOAD16(tside0[2 * i], tvo, trs_l, so, 0);
         E_BLOAD16(tside0[2 * i + 1], tvo, trs_l, so, 64);
       }
-      E_WAIT8(8, side1);    // newer: the 8 loads just issued
+      E_WAIT8(12, side0);   // residual rows 0-63 (phase 4 of the last K-tile): newer are B00 / B10 (4) and the 8 loads above
+      pass1a(std::integral_constant<int, 0>{});
+      E_WAIT8(0, side1);    // residual rows 64-127 (issued halfway through pass 1a of rows 0-63): nothing newer
       pass1a(std::integral_constant<int, 1>{});
-      // gamma / beta of the lane's 16 columns ([2 hb + half]), rstd of its eight rows, t rows 64-127
-      const ei4v grs = ersrc(q.gamma + 256 * wr + 64 * wc, 64 * 4), ers = ersrc(q.beta + 256 * wr + 64 * wc, 64 * 4);
-      const ei4v rrs = ersrc(q.rstd + tm0, 128 * 4);
-      const unsigned gvoff = (unsigned)(8 * ep * 4), rvo = (unsigned)(er * 4);
-      eu4v cg[4], cb[4];
-      unsigned rsr[8];
-      E_BLOAD16(cg[0], gvoff, grs, 0, 0); E_BLOAD16(cg[1], gvoff, grs, 0, 16); E_BLOAD16(cg[2], gvoff, grs, 0, 128); E_BLOAD16(cg[3], gvoff, grs, 0, 144);
-      E_BLOAD16(cb[0], gvoff, ers, 0, 0); E_BLOAD16(cb[1], gvoff, ers, 0, 16); E_BLOAD16(cb[2], gvoff, ers, 0, 128); E_BLOAD16(cb[3], gvoff, ers, 0, 144);
-      E_BLOAD4(rsr[0], rvo, rrs, 0, 0); E_BLOAD4(rsr[1], rvo, rrs, 0, 64); E_BLOAD4(rsr[2], rvo, rrs, 0, 128); E_BLOAD4(rsr[3], rvo, rrs, 0, 192);
-      E_BLOAD4(rsr[4], rvo, rrs, 256, 0); E_BLOAD4(rsr[5], rvo, rrs, 256, 64); E_BLOAD4(rsr[6], rvo, rrs, 256, 128); E_BLOAD4(rsr[7], rvo, rrs, 256, 192);
 #pragma unroll
-      for (int i = 0; i < 4; i++) {
+      for (int i = 0; i < 4; i++) {   // t rows 64-127 (beside rows 64-127 of the accumulators they spill 13 registers: they arrive under pass 1b of rows 0-63)
         const int so = (64 + 16 * i) * tpitch_l;
         E_BLOAD16(tside1[2 * i], tvo, trs_l, so, 0);
         E_BLOAD16(tside1[2 * i + 1], tvo, trs_l, so, 64);
       }
-      // t rows 0-63 and the constants: newer are the 8 loads of t rows 64-127
+      // t rows 0-63 and the constants (issued in pass 1a's last quarter): newer are the 8 loads just issued
       E_WAIT8(8, tside0);
       E_WAIT4(8, cg);
       E_WAIT4(8, cb);
-      asm volatile("s_waitcnt vmcnt(8)" : "+v"(rsr[0]), "+v"(rsr[1]), "+v"(rsr[2]), "+v"(rsr[3]), "+v"(rsr[4]), "+v"(rsr[5]), "+v"(rsr[6]), "+v"(rsr[7]) :: "memory");
       // pair e of block hb <-> columns 32 hb + 8 ep + 2 e, + 1
       auto Gp = [&](int hb, int e) -> ef2v { return (ef2v){__uint_as_float(cg[2 * hb + (e >> 1)][2 * (e & 1)]), __uint_as_float(cg[2 * hb + (e >> 1)][2 * (e & 1) + 1])}; };
       auto Bp = [&](int hb, int e) -> ef2v { return (ef2v){__uint_as_float(cb[2 * hb + (e >> 1)][2 * (e & 1)]), __uint_as_float(cb[2 * hb + (e >> 1)][2 * (e & 1) + 1])}; };
@@ -1178,6 +1183,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_n512(GemmP p, LnP q) {
             const eu4v tw = ha ? tside1[2 * i + hb] : tside0[2 * i + hb];
 #pragma unroll
             for (int e = 0; e < 4; e++) {
+              if (LNB_ABL & 2) { if (e == 0) { a1[0] += __uint_as_float(dtp[ha][i][hb][0]); a2[0] += __uint_as_float(tw[0]); } continue; }
               const ef2v d = lo2(dtp[ha][i][hb][e]);
               const ef2v u = lo2(tw[e]) - Bp(hb, e);
               a1 = __builtin_elementwise_fma(d, Gp(hb, e), a1);
@@ -1192,20 +1198,18 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_n512(GemmP p, LnP q) {
         }
       }
       // ---- pass 2.  The rows of t again, chunk by chunk (c = 2 hb + ha: rows 64 ha + 16 i + er, the 16-byte piece of block hb), one chunk ahead
-      eu4v tc[2][4];
+      unsigned rsc[3][4];   // rstd of a chunk's four rows, loaded two chunks ahead (held from pass 1a on they were 8 registers too many)
       auto tload = [&](auto c_c) __attribute__((always_inline)) {
-        constexpr int c = decltype(c_c)::value, hb = c >> 1, ha = c & 1;
-        auto& tc_ = tc;   // (hipcc does not capture a variable that a generic lambda names only as an asm operand)
-        const unsigned tvo_ = tvo;
-        const ei4v trs_ = trs_l;
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-          const int so = (64 * ha + 16 * i) * tpitch_l;
-          if (hb) E_BLOAD16(tc_[c & 1][i], tvo_, trs_, so, 64); else E_BLOAD16(tc_[c & 1][i], tvo_, trs_, so, 0);
-        }
+        constexpr int c = decltype(c_c)::value, ha = c & 1;
+        auto& rsc_ = rsc;   // (hipcc does not capture a variable that a generic lambda names only as an asm operand)
+        const unsigned rvo_ = rvo;
+        const ei4v rrs_ = rrs;
+        E_BLOAD4(rsc_[c % 3][0], rvo_, rrs_, 256 * ha, 0); E_BLOAD4(rsc_[c % 3][1], rvo_, rrs_, 256 * ha, 64);
+        E_BLOAD4(rsc_[c % 3][2], rvo_, rrs_, 256 * ha, 128); E_BLOAD4(rsc_[c % 3][3], rvo_, rrs_, 256 * ha, 192);
       };
       tload(std::integral_constant<int, 0>{});
       tload(std::integral_constant<int, 1>{});
+      tload(std::integral_constant<int, 2>{});
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       N_BAR();
       auto colred8 = [&](const ef2v (&A)[4]) -> float {
@@ -1240,6 +1244,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_n512(GemmP p, LnP q) {
 #pragma unroll
           for (int e = 0; e < 4; e++) {
             G[e] = Gp(hb, e); Bt[e] = Bp(hb, e);
+            asm volatile("" : "+v"(G[e]));   // (opaque here: the compiler otherwise takes the reciprocals of BOTH blocks in front of pass 1b and spills them)
             // (v_rcp_f32, one ulp: the correctly rounded quotient is a dozen instructions per column and tile)
             IG[e][0] = G[e][0] != 0.f ? __builtin_amdgcn_rcpf(G[e][0]) : 0.f;
             IG[e][1] = G[e][1] != 0.f ? __builtin_amdgcn_rcpf(G[e][1]) : 0.f;
@@ -1251,13 +1256,19 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_n512(GemmP p, LnP q) {
           const int r = 64 * ha + 16 * i + er;
           const float c1 = quad(X[(2 * ep) * 260 + r] + X[(2 * ep + 1) * 260 + r]) * (1.0f / 512.f);
           const float c2 = quad(X[(2 * ep) * 260 + 128 + r] + X[(2 * ep + 1) * 260 + 128 + r]) * (1.0f / 512.f);
-          const float rs = __uint_as_float(rsr[4 * ha + i]);
+          const float rs = __uint_as_float(rsc[c % 3][i]);
           const ef2v c1v = {-c1, -c1}, c2v = {-c2, -c2}, rsv = {rs, rs};
           const int so = (64 * ha + 16 * i) * cpitch;
-          const eu4v tw = tc[c & 1][i];
+          // The rows of t stay in their registers from pass 1b (a second load of them was a second trip to HBM - a round of tiles sweeps the
+          // XCD's L2 - and the launch runs at the memory system's rate: it was what the epilogue cost).  Both packed rows are made opaque again:
+          // otherwise the unpacked f32 pairs of pass 1b are KEPT for this pass - in scratch - instead of two shifts per pair here
+          if (ha) asm volatile("" : "+v"(tside1[2 * i + hb])); else asm volatile("" : "+v"(tside0[2 * i + hb]));
+          const eu4v tw = ha ? tside1[2 * i + hb] : tside0[2 * i + hb];
+          asm volatile("" : "+v"(dtp[ha][i][hb]));
           eu4v od;
 #pragma unroll
           for (int e = 0; e < 4; e++) {
+            if (LNB_ABL & 4) { od[e] = dtp[ha][i][hb][e] ^ tw[e]; AX[e][0] += rs + c1 + c2; continue; }
             const ef2v d = lo2(dtp[ha][i][hb][e]);
             const ef2v xh = (lo2(tw[e]) - Bt[e]) * IG[e];
             ef2v o = __builtin_elementwise_fma(d, G[e], c1v);
@@ -1270,20 +1281,22 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_n512(GemmP p, LnP q) {
           if (hb) E_BSTORE16(od, cvo_, crs_, so, 64); else E_BSTORE16(od, cvo_, crs_, so, 0);
         }
         if constexpr (ha == 1) {
+          if (LNB_ABL & 1) { tot_g[hb] = AG[0][0] + AG[3][1]; tot_b[hb] = AB[0][0] + AB[3][1]; tot_x[hb] = AX[0][0] + AX[3][1]; }
+          else {
           tot_g[hb] = colred8(AG);
           tot_b[hb] = colred8(AB);
           tot_x[hb] = colred8(AX);
+          }
         }
       };
-      E_WAIT4(4, tc[0]);                       // chunk 0: newer is chunk 1 (4)
+      E_WAIT4(8, rsc[0]);                                  // chunk 0's rstd: newer are chunks 1 and 2 (4 + 4)
       chunk(std::integral_constant<int, 0>{});
-      tload(std::integral_constant<int, 2>{});             // (chunk 0's registers)
-      E_WAIT4(8, tc[1]);                       // chunk 1: newer are chunk 0's stores (4) and chunk 2 (4)
+      tload(std::integral_constant<int, 3>{});             // (chunk 0's registers)
+      E_WAIT4(12, rsc[1]);                                 // chunk 1: newer are chunk 2 (4), chunk 0's stores (4), chunk 3 (4)
       chunk(std::integral_constant<int, 1>{});
-      tload(std::integral_constant<int, 3>{});
-      E_WAIT4(8, tc[0]);                       // chunk 2: newer are chunk 1's stores and chunk 3
+      E_WAIT4(12, rsc[2]);                                 // chunk 2: newer are chunk 0's stores, chunk 3, chunk 1's stores
       chunk(std::integral_constant<int, 2>{});
-      E_WAIT4(4, tc[1]);                       // chunk 3: newer are chunk 2's stores
+      E_WAIT4(8, rsc[0]);                                  // chunk 3: newer are chunk 1's and chunk 2's stores
       chunk(std::integral_constant<int, 3>{});
       // every wave has read the exchange area before any wave's next tile refills the slot (LDS-DMA in phase 1 of its first K-tile)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
