@@ -372,6 +372,7 @@ extern int g_attn_lh;
 extern int g_gemm_splitk_ws;          // gemm_e.hip
 extern int g_gemm_splitk_table;
 extern int g_gemm_nw;
+extern int g_gemm_d128;
 static int g_gemm_policy = 0;         // 0 = auto, 1 = 128x128x64 persistent kernel (this file), 4 = gemm_bf16_o128, 7 = gemm_bf16_r256, 20 = gemm_bf16_e256
 static int g_gemm_e256_min = 192;     // auto: stored products with at least this many 256x256 tiles take the eight-phase kernel (0 = never)
 static int g_gemm_e_splitk_min = 4;   // ... and split-K products (reduction >= 32768 rows) with at least this many output tiles
@@ -387,6 +388,7 @@ extern "C" int pero_set_option(const char* name, int value) {
   if (name && !strcmp(name, "splitk_workspace")) { g_gemm_splitk_ws = value; return PERO_OK; }
   if (name && !strcmp(name, "splitk_table")) { g_gemm_splitk_table = value; return PERO_OK; }
   if (name && !strcmp(name, "gemm_nw")) { g_gemm_nw = value; return PERO_OK; }
+  if (name && !strcmp(name, "gemm_d128")) { g_gemm_d128 = value; return PERO_OK; }
   if (name && !strcmp(name, "gemm_e256_min")) { g_gemm_e256_min = value; return PERO_OK; }
   if (name && !strcmp(name, "gemm_e_splitk_min")) { g_gemm_e_splitk_min = value; return PERO_OK; }
   if (name && !strcmp(name, "splitk_xcd")) { g_pero_splitk_xcd = value; return PERO_OK; }
@@ -536,6 +538,13 @@ static int gemm_dispatch(const void* A, const void* B, void* C, const float* bia
     // the row-complete 128 x 512 tile (opt-in): N = 512 stored products with the plain / residual epilogue
     if (!atomic && g_gemm_nw && !want_cs && out_dtype == PERO_BF16 && pero_launch_gemm_n512(p, batch, ta, tb, false, st)) {
       PERO_CHECK_LAUNCH("pero_gemm(n512)");
+      return PERO_OK;
+    }
+    // two workgroups per CU on 256 x 128 tiles (opt-in): stored products with few K-tiles per tile, plain / ReLU / bit-mask epilogues
+    if (!atomic && g_gemm_d128 && out_dtype == PERO_BF16 && !want_rd && K <= g_gemm_d128 * 64LL && (auto_or || g_gemm_policy == 20) &&
+        pero_launch_gemm_d128(pc, batch, ta, tb, false, st)) {
+      *colsum_fused = want_cs;
+      PERO_CHECK_LAUNCH("pero_gemm(d128)");
       return PERO_OK;
     }
     // ... and stored bf16 products with every fused epilogue

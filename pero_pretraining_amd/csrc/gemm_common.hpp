@@ -37,6 +37,8 @@ bool pero_launch_gemm_e256(const GemmP& p, long long batch, int k_split, bool ta
 long long pero_gemm_e256_splitk_ws_bytes(long long M, long long N, long long K, int k_split);
 // host entry of the row-complete 128 x 512 tile (gemm_e.hip, opt-in "gemm_nw"): N = 512 stored products with the plain / residual epilogue
 bool pero_launch_gemm_n512(const GemmP& p, long long batch, bool ta, bool tb, bool out_f32, hipStream_t st);
+// host entry of the 256 x 128 tile with two workgroups per CU (gemm_e.hip, opt-in "gemm_d128" = the largest K / 64 that takes it)
+bool pero_launch_gemm_d128(const GemmP& p, long long batch, bool ta, bool tb, bool out_f32, hipStream_t st);
 bool pero_launch_gemm_n512_ln(const GemmP& p, void* t, long long ldt, float* mean, float* rstd, const float* gamma, const float* beta, float eps,
                               hipStream_t st);
 bool pero_launch_gemm_n512_lnb(const GemmP& p, const void* t, long long ldt, const float* rstd, const float* gamma, const float* beta, float* work,

@@ -587,7 +587,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p, int ks) {
       return;
     }
     {
-      const ei4v crs = ersrc((bf16raw*)p.C + tm0 * p.ldc + tn0, (unsigned)(256 * p.ldc * 2));
+      // (VAR 1, timing probe: every tile of a workgroup lands on the workgroup's FIRST tile - the stores are issued and acknowledged, the lines stay in L2)
+      const ei4v crs = (VAR & 1) ? ersrc((bf16raw*)p.C + (long long)((blockIdx.x >> 3) * 256) * p.ldc + (blockIdx.x & 7) * 256, (unsigned)(256 * p.ldc * 2))
+                                 : ersrc((bf16raw*)p.C + tm0 * p.ldc + tn0, (unsigned)(256 * p.ldc * 2));
       const int cpitch = (int)(p.ldc * 2);
       // bias of the lane's columns as the accumulators hold them: 64 wc + 32 hb + 16 j + 4 (lane >> 4) .. + 3
       f4v bx[2][2];
@@ -824,6 +826,417 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p, int ks) {
 #undef E_BAR
 #undef E_LGKM0
 #undef E_STAMP
+}
+
+// =====================================================================================================================================
+// TWO INDEPENDENT WORKGROUPS PER CU (round 4, opt-in: pero_set_option("gemm_d128", 1)) for the stored K-contiguous products with FEW K-tiles per
+// output tile (K = 512: eight).  In gemm_bf16_e256 the eight waves of the one workgroup per CU share one barrier domain: all of them are in
+// the tile's epilogue together and the matrix pipe idles for a quarter of the tile (5-6 k of 35 k cycles, plus the main
+// loop slowed by the whole chip storing at once).  Here a workgroup is FOUR waves (2 (M) x 2 (N), one per SIMD) on a 256 x 128 tile - the
+// same 128 x 64 outputs, fragment reads, MFMAs and epilogue per wave as in the 256 x 256 tile - with half the LDS (80 KiB), so that two
+// workgroups share a CU: two waves per SIMD as before, but from different barrier domains, and one workgroup's epilogue runs under the
+// other's main loop.  Per K-tile A0 A1 (128 rows x 64 k, 16 KiB) and B0 B1 (64 columns x 64 k, 8 KiB); the A halves roll through a ring of
+// THREE 16 KiB slots, the B halves through three 8 KiB slots (half a = 2 t + h of the stream sits in slot a % 3):
+//     P1: wait A0(t) B0(t) | barrier | read B0 A0 -> A0 x B0                   P3: barrier | read A1 ; issue B0(t+2) -> B1(t)'s slot -> A1 x B1
+//     P2: wait A1(t) B1(t) | barrier | read B1 ; issue A1(t+1) B1(t+1) -> the   P4: barrier | issue A0(t+2) -> A1(t)'s slot        -> A1 x B0
+//         slots of A0(t) B0(t)                                    -> A0 x B1
+// One barrier per phase: it stands behind every wave's lgkmcnt(0) of the phase before (the slot restaged behind it has been read by all)
+// and behind every wave's counted vmcnt (the half tiles read behind it have landed for all).  The LDS-DMA stream is one sequence over
+// (tile, K-tile) pairs as in gemm_bf16_e256, 12 instructions per wave and K-tile, never drained; the epilogue's stores (and the next
+// tile's bias row) enter the same in-order counter and the first three waits of a tile count them out.
+#define D_BM 256
+#define D_BN 128
+#define D_AH 16384                     // A half tile
+#define D_BH 8192                      // B half tile
+#define D_BRING (3 * D_AH)
+#define D_AUX (D_BRING + 3 * D_BH)     // 4 KiB: two copies (tile parity) of the tile's 128 bias floats (1 KiB each: lanes 32-63 repeat lanes 0-31) | EP_GATE_BITS: the mask LUT
+#define D_XSTG (D_AUX + 4096)          // 4 x 1 KiB: each wave's staging image of the epilogue's lane transpose (the two units of a row group one after the other)
+#define D_LDS_BYTES (D_XSTG + 4096)    // 81 920 = half of the CU's LDS
+
+template <int EPI> struct DCnt {
+  static constexpr int ML = EPI == EP_GATE_BITS ? 8 : 0;                                   // mask loads (phase 1 of the last K-tile)
+  static constexpr int L0 = (EPI == EP_RESID || EPI == EP_ROWDOT) ? 8 : 0;                 // side loads of rows 0-63 (phase 4 of the last K-tile, ahead of A0(t+2)) ...
+  static constexpr int L1 = L0;                                                            // ... and of rows 64-127 (start of the epilogue)
+  static constexpr int ST = 16 + (EPI == EP_RELU_BITS ? 8 : 0) + (EPI == EP_ROWDOT ? 8 : 0);   // stores / atomics of a tile
+};
+
+template <int EPI, int VAR>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_d128(GemmP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  typedef DCnt<EPI> CN;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int ntn = (int)(p.N / D_BN);
+  const int nt = (int)(p.M / D_BM) * ntn;
+  const int G = gridDim.x;  // multiple of 8
+  const int q8 = nt >> 3, r8 = nt & 7;
+  const int nk = (int)(p.K / E_BK);  // >= 3 (launcher)
+  const long long lda2 = p.lda * 2, ldb2 = p.ldb * 2;
+  // LDS-DMA: a wave-instruction fills 8 rows x 128 B (lane-linear; the chunk swizzle is on the SOURCE address); the 256 threads cover 32 rows,
+  // an A half is four such pieces (rows 0, 32 | 128, 160 of the tile + 64 h), a B half two (columns 0 | 64 of the tile + 32 h)
+  const unsigned offA = (unsigned)(((tid >> 3) * p.lda + (((tid & 7) ^ ((tid >> 3) & 7)) << 3)) * 2);
+  const unsigned offB = (unsigned)(((tid >> 3) * p.ldb + (((tid & 7) ^ ((tid >> 3) & 7)) << 3)) * 2);
+  const bool colsum = EPI == EP_GATE_BITS && (p.flags & PERO_GEMM_COLSUM);
+
+  auto tile_of = [&](int T, long long& tm0, long long& tn0) {
+    const int xcd = T & 7, loc = T >> 3;
+    const int id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
+    tm0 = (long long)(id / ntn) * D_BM;
+    tn0 = (long long)(id % ntn) * D_BN;
+  };
+  int T = blockIdx.x;
+  if (T >= nt) return;
+  long long tm0, tn0, nm0, nn0;
+  tile_of(T, tm0, tn0);
+  bool has_next = T + G < nt;
+  tile_of(has_next ? T + G : T, nm0, nn0);
+
+  const unsigned rc0 = (unsigned)((lane & 15) * 128 + ((((lane >> 4)) ^ (lane & 7)) << 4));  // fragment read offset inside a half tile (see gemm_bf16_e256)
+  const int li = lane & 15, lq = lane >> 4;
+  f4v acc[2][2][4][2];  // [A half][B half][i][j]
+  bf8v fa[4][2], fb0[2][2], fb1[2][2];
+#define D_RD_A(BASE_)                                                                            \
+  _Pragma("unroll") for (int i_ = 0; i_ < 4; i_++) {                                             \
+    fa[i_][0] = *(const bf8v*)((BASE_) + (64 * wr + 16 * i_) * 128 + rc0);                       \
+    fa[i_][1] = *(const bf8v*)((BASE_) + (64 * wr + 16 * i_) * 128 + (rc0 ^ 64u));               \
+  }
+#define D_RD_B(F_, BASE_)                                                                        \
+  _Pragma("unroll") for (int j_ = 0; j_ < 2; j_++) {                                             \
+    F_[j_][0] = *(const bf8v*)((BASE_) + (32 * wc + 16 * j_) * 128 + rc0);                       \
+    F_[j_][1] = *(const bf8v*)((BASE_) + (32 * wc + 16 * j_) * 128 + (rc0 ^ 64u));               \
+  }
+#define D_MFMA(HA_, HB_, F_)                                                                                              \
+  __builtin_amdgcn_s_setprio(1);                                                                                          \
+  _Pragma("unroll") for (int s_ = 0; s_ < 2; s_++)                                                                        \
+  _Pragma("unroll") for (int i_ = 0; i_ < 4; i_++)                                                                        \
+  _Pragma("unroll") for (int j_ = 0; j_ < 2; j_++)                                                                        \
+    acc[HA_][HB_][i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F_[j_][s_], fa[i_][s_], acc[HA_][HB_][i_][j_], 0, 0, 0); \
+  __builtin_amdgcn_s_setprio(0);
+#define D_BAR()                                  \
+  __builtin_amdgcn_sched_barrier(0);             \
+  __builtin_amdgcn_s_barrier();                  \
+  __builtin_amdgcn_sched_barrier(0);
+#define D_LGKM0()                                          \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       \
+  __builtin_amdgcn_sched_barrier(0);
+#define D_VM(n_) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(n_) : "memory")
+
+  const unsigned char* cA = (const unsigned char*)p.A + tm0 * lda2;
+  const unsigned char* cB = (const unsigned char*)p.B + tn0 * ldb2;
+  const unsigned char* nA = (const unsigned char*)p.A + nm0 * lda2;
+  const unsigned char* nB = (const unsigned char*)p.B + nn0 * ldb2;
+  auto glds = [&](const unsigned char* src, unsigned off, unsigned char* dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + off), (__attribute__((address_space(3))) void*)(dst), 16, 0, 0);
+  };
+  // half h of K-tile u of the current tile (u >= nk: of the next one; a workgroup's last tile "prefetches" its own first K-tiles again) -> ring slot
+  auto issueA = [&](int u, int h, int slot) {
+    const bool nx = u >= nk;
+    const unsigned char* src = (nx ? nA : cA) + (long long)(nx ? u - nk : u) * (E_BK * 2) + h * (64 * lda2);
+    unsigned char* dst = smem + slot * D_AH + wave * 1024;
+    glds(src, offA, dst); glds(src + 32 * lda2, offA, dst + 4096); glds(src + 128 * lda2, offA, dst + 8192); glds(src + 160 * lda2, offA, dst + 12288);
+  };
+  auto issueB = [&](int u, int h, int slot) {
+    const bool nx = u >= nk;
+    const unsigned char* src = (nx ? nB : cB) + (long long)(nx ? u - nk : u) * (E_BK * 2) + h * (32 * ldb2);
+    unsigned char* dst = smem + D_BRING + slot * D_BH + wave * 1024;
+    glds(src, offB, dst); glds(src + 64 * ldb2, offB, dst + 4096);
+  };
+  const bool use_bias = (EPI <= EP_RELU_BITS) && p.bias;
+  int tix = 0;
+  auto issue_bias = [&](long long bn) {  // 128 floats = 32 lanes x 16 B (lanes 32-63 fetch them again), into this tile's parity copy
+    const float* src = use_bias ? p.bias + bn : (const float*)p.B;  // (no bias: any readable address; the copy is not used)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const unsigned char*)src + (lane & 31) * 16),
+                                     (__attribute__((address_space(3))) void*)(smem + D_AUX + (EPI == EP_GATE_BITS ? 0 : (tix & 1) * 1024)), 16, 0, 0);
+  };
+  if (EPI == EP_GATE_BITS) {   // bit e of a mask byte keeps column e of the lane's 8: dword k holds columns 2k (low half) and 2k + 1
+    eu4v m;
+#pragma unroll
+    for (int k = 0; k < 4; k++) m[k] = (((tid >> (2 * k)) & 1) ? 0x0000ffffu : 0u) | (((tid >> (2 * k + 1)) & 1) ? 0xffff0000u : 0u);
+    *(eu4v*)(smem + D_AUX + tid * 16) = m;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // visible to every wave behind the first barrier
+  }
+  // ---- prologue, in the stream's steady-state order: B0(0) A0(0) | A1(0) B1(0) | B0(1) | A0(1)
+  issueB(0, 0, 0); issueA(0, 0, 0); issueA(0, 1, 1); issueB(0, 1, 1); issueB(1, 0, 2); issueA(1, 0, 2);
+  int s = 0;           // ring slot of the current K-tile's A0 / B0
+  bool first = true;
+
+  // epilogue addressing: see gemm_bf16_e256 (the wave's outputs are rows 128 wr .., columns 64 wc .. of the tile)
+  const int cq = ((lq & 1) << 1) | (lq >> 1);
+  const int er = lane >> 2, ep = lane & 3;
+  const unsigned cvo = (unsigned)(((128 * wr + er) * p.ldc + 64 * wc + 8 * ep) * 2);
+  const unsigned gvo = (unsigned)(((128 * wr + er) * (EPI == EP_RESID ? p.ldr : p.ldg) + 64 * wc + 8 * ep) * 2);
+  const unsigned mvo = (unsigned)((128 * wr + er) * p.ldg + 8 * wc);
+  unsigned char* const xstg = smem + D_XSTG + wave * 1024;
+  const unsigned xw16 = (unsigned)(li * 64 + ((cq ^ ((li >> 1) & 3)) << 4));
+  const unsigned xr16 = (unsigned)(er * 64 + ((ep ^ ((er >> 1) & 3)) << 4));
+  const unsigned char* const lutp = smem + D_AUX;
+  unsigned sel_lo = 0x00003f80u, sel_hi = 0x3f800000u;
+  asm volatile("" : "+s"(sel_lo), "+s"(sel_hi));
+  float cs_run = 0.f;
+  long long cs_tn0 = -1;
+  eu4v side0[8], side1[8];
+  eu2v sm0[4], sm1[4];
+  (void)gvo; (void)side0; (void)side1;
+
+  for (;;) {
+    constexpr int EB = EPI == EP_GATE_BITS ? 0 : 1;   // the tile's bias row is part of the stream (the gate takes none: its LUT lives there)
+    if (EB) issue_bias(tn0);
+    const int spitch = (int)(EPI == EP_RESID ? p.ldr * 2 : EPI == EP_ROWDOT ? p.ldg * 2 : p.ldg);  // bytes per row
+    const ei4v srs = ersrc(EPI == EP_RESID ? (const void*)((const bf16raw*)p.resid + tm0 * p.ldr + tn0)
+                           : EPI == EP_ROWDOT ? (const void*)((const bf16raw*)p.gate + tm0 * p.ldg + tn0)
+                           : (const void*)((const unsigned char*)p.gate + tm0 * p.ldg + (tn0 >> 3)),
+                           (unsigned)(256 * spitch));
+    // one K-tile; KIND 0 / 1: the tile's first two (their waits count the previous epilogue out), 3: its last (peeled: mask / side loads), 2: the others
+    auto ktile = [&](auto kind_c, const int t) __attribute__((always_inline)) {
+      constexpr int kind = decltype(kind_c)::value;
+      constexpr bool last = kind == 3;
+      const int s1 = s == 2 ? 0 : s + 1, s2 = s == 0 ? 2 : s - 1;
+      const unsigned char* const A0p = smem + s * D_AH;
+      const unsigned char* const A1p = smem + s1 * D_AH;
+      const unsigned char* const B0p = smem + D_BRING + s * D_BH;
+      const unsigned char* const B1p = smem + D_BRING + s1 * D_BH;
+      // P1: A0(t), B0(t) have landed - in flight behind them: 12 of the stream (+ the previous epilogue and this tile's bias row for K-tiles 0, 1)
+      if (kind == 0) { if (first) D_VM(12 + EB); else D_VM(12 + CN::ML + CN::L0 + CN::L1 + CN::ST + EB); }
+      else if (kind == 1) { if (first) D_VM(12 + EB); else D_VM(12 + CN::L1 + CN::ST + EB); }
+      else D_VM(12);
+      D_BAR();
+      D_RD_B(fb0, B0p);
+      __builtin_amdgcn_sched_barrier(0);
+      D_RD_A(A0p);
+      if (EPI == EP_GATE_BITS && last) {  // the tile's mask bytes (8 per row and wave)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const int so0 = 16 * i * spitch, so1 = (64 + 16 * i) * spitch;
+          E_BLOAD8(sm0[i], mvo, srs, so0, 0);
+          E_BLOAD8(sm1[i], mvo, srs, so1, 0);
+        }
+      }
+      D_LGKM0();
+      D_MFMA(0, 0, fb0);
+      // P2: A1(t), B1(t) have landed - behind them B0(t+1), A0(t+1) (+ the mask loads)
+      if (kind == 0) { if (first) D_VM(6 + EB); else D_VM(6 + CN::L0 + CN::L1 + CN::ST + EB); }
+      else D_VM(6 + (last ? CN::ML : 0));
+      D_BAR();
+      D_RD_B(fb1, B1p);
+      issueA(t + 1, 1, s); issueB(t + 1, 1, s);
+      D_LGKM0();
+      D_MFMA(0, 1, fb1);
+      // P3
+      D_BAR();
+      D_RD_A(A1p);
+      issueB(t + 2, 0, s1);
+      D_LGKM0();
+      D_MFMA(1, 1, fb1);
+      // P4
+      D_BAR();
+      if (CN::L0 && last) {  // side inputs of the wave's rows 0-63
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const int so = 16 * i * spitch;
+          E_BLOAD16(side0[2 * i], gvo, srs, so, 0);
+          E_BLOAD16(side0[2 * i + 1], gvo, srs, so, 64);
+        }
+      }
+      issueA(t + 2, 0, s1);
+      D_MFMA(1, 0, fb0);
+      s = s2;
+    };
+#pragma unroll
+    for (int ha = 0; ha < 2; ha++)
+#pragma unroll
+      for (int hb = 0; hb < 2; hb++)
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+          for (int j = 0; j < 2; j++) acc[ha][hb][i][j] = (f4v){0.f, 0.f, 0.f, 0.f};
+    ktile(std::integral_constant<int, 0>{}, 0);
+    ktile(std::integral_constant<int, 1>{}, 1);
+    for (int t = 2; t < nk - 1; t++) ktile(std::integral_constant<int, 2>{}, t);
+    ktile(std::integral_constant<int, 3>{}, nk - 1);
+    first = false;
+
+    // ---- epilogue, straight from the accumulators: gemm_bf16_e256's, unit by unit (no barrier inside: the other workgroup of the CU has the matrix pipe meanwhile)
+    {
+      static_assert(EPI == EP_PLAIN || EPI == EP_RELU || EPI == EP_RELU_BITS || EPI == EP_GATE_BITS, "epilogue mode");
+      const ei4v crs = ersrc((bf16raw*)p.C + tm0 * p.ldc + tn0, (unsigned)(256 * p.ldc * 2));
+      const int cpitch = (int)(p.ldc * 2);
+      const unsigned char* const biasl = smem + D_AUX + (tix & 1) * 1024;
+      f4v bx[2][2];
+#pragma unroll
+      for (int hb = 0; hb < 2; hb++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          bx[hb][j] = (f4v){0.f, 0.f, 0.f, 0.f};
+          if (use_bias) bx[hb][j] = *(const f4v*)(biasl + (64 * wc + 32 * hb + 16 * j + 4 * lq) * 4);
+        }
+      float cs[2][8];
+#pragma unroll
+      for (int hb = 0; hb < 2; hb++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) cs[hb][e] = 0.f;
+#pragma unroll
+      for (int ha = 0; ha < 2; ha++) {
+        if (EPI == EP_GATE_BITS && ha == 0) {   // behind the mask loads: phases 2-4 of the last K-tile (6 + 2 + 4)
+          E_WAIT4(12, sm0);
+          E_WAIT4(12, sm1);
+        }
+#pragma unroll
+        for (int ib = 0; ib < 4; ib += 2) {
+          eu4v o[2][2];
+          eu4v kp[2][2];
+          (void)kp;
+#pragma unroll
+          for (int ii = 0; ii < 2; ii++)
+#pragma unroll
+            for (int hb = 0; hb < 2; hb++) {
+              const int i = ib + ii;
+              if (EPI == EP_GATE_BITS) {
+                const eu2v mm = ha ? sm1[i] : sm0[i];
+                const unsigned byte = __builtin_amdgcn_ubfe(hb ? mm[1] : mm[0], 8u * (unsigned)ep, 8u);
+                kp[ii][hb] = *(const eu4v*)(lutp + (byte << 4));
+              }
+              const f4v x = EPI <= EP_RELU_BITS ? acc[ha][hb][i][0] + bx[hb][0] : acc[ha][hb][i][0];
+              const f4v y = EPI <= EP_RELU_BITS ? acc[ha][hb][i][1] + bx[hb][1] : acc[ha][hb][i][1];
+              unsigned px0 = pack2bf(x[0], x[1]), px1 = pack2bf(x[2], x[3]);
+              unsigned py0 = pack2bf(y[0], y[1]), py1 = pack2bf(y[2], y[3]);
+              if (EPI == EP_RELU || EPI == EP_RELU_BITS) { px0 = epk_relu(px0); px1 = epk_relu(px1); py0 = epk_relu(py0); py1 = epk_relu(py1); }
+              auto s0 = __builtin_amdgcn_permlane16_swap(px0, py0, false, false);
+              auto s1 = __builtin_amdgcn_permlane16_swap(px1, py1, false, false);
+              // lane transpose through the wave's staging image (one image for every unit: a wave's LDS instructions execute in order)
+              *(eu4v*)(xstg + xw16) = (eu4v){s0[0], s1[0], s0[1], s1[1]};
+              o[ii][hb] = *(const eu4v*)(xstg + xr16);
+            }
+#pragma unroll
+          for (int ii = 0; ii < 2; ii++) {
+            const int i = ib + ii;
+            const int so = (64 * ha + 16 * i) * cpitch;
+            unsigned mL = 0, mH = 0;
+#pragma unroll
+            for (int hb = 0; hb < 2; hb++) {
+              eu4v& ou = o[ii][hb];
+              if (EPI == EP_RELU_BITS) {
+                unsigned z = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                  const unsigned m = epk_nonzero(ou[k]);
+                  z |= m << (2 * k);
+                }
+                const unsigned byte = (z & 0x55u) | ((z >> 15) & 0xaau);
+                if (hb == 0) mL = byte << (8 * ep); else mH = byte << (8 * ep);
+              }
+              if (EPI == EP_GATE_BITS) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                  ou[k] &= kp[ii][hb][k];
+                  cs[hb][2 * k] = edot2(ou[k], sel_lo, cs[hb][2 * k]);
+                  cs[hb][2 * k + 1] = edot2(ou[k], sel_hi, cs[hb][2 * k + 1]);
+                }
+              }
+              if (VAR & 4) {  // ablation: no stores (the values stay live)
+                asm volatile("" :: "v"(ou[0]), "v"(ou[1]), "v"(ou[2]), "v"(ou[3]));
+                if (i + hb == 0) { if (hb) E_BSTORE16(ou, cvo, crs, so, 64); else E_BSTORE16(ou, cvo, crs, so, 0); }
+              } else {
+                if (hb) E_BSTORE16(ou, cvo, crs, so, 64); else E_BSTORE16(ou, cvo, crs, so, 0);
+              }
+            }
+            if (EPI == EP_RELU_BITS) {
+              mL |= (unsigned)__builtin_amdgcn_mov_dpp((int)mL, 0xB1, 0xf, 0xf, false);  // quad_perm [1,0,3,2]
+              mH |= (unsigned)__builtin_amdgcn_mov_dpp((int)mH, 0xB1, 0xf, 0xf, false);
+              mL |= (unsigned)__builtin_amdgcn_mov_dpp((int)mL, 0x4E, 0xf, 0xf, false);  // quad_perm [2,3,0,1]
+              mH |= (unsigned)__builtin_amdgcn_mov_dpp((int)mH, 0x4E, 0xf, 0xf, false);
+              const eu2v mo = {mL, mH};
+              const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc((unsigned char*)p.gate + tm0 * p.ldg + (tn0 >> 3), 0, (int)(256 * p.ldg), 0x00020000);
+              __builtin_amdgcn_raw_buffer_store_b64(mo, mrs, mvo, (64 * ha + 16 * i) * (int)p.ldg, 0);
+            }
+          }
+        }
+      }
+      if (colsum) {   // column sums of the wave's 128 rows: see gemm_bf16_e256
+        float w8[8], w4[4], w2[2];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(cs[0][j]), __float_as_uint(cs[1][j]), false, false);
+          w8[j] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(w8[j]), __float_as_uint(w8[j + 4]), false, false);
+          w4[j] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          const float s0 = w4[j] + __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(w4[j]), 0x128, 0xf, 0xf, false));
+          const float s1 = w4[j + 2] + __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(w4[j + 2]), 0x128, 0xf, 0xf, false));
+          w2[j] = (er & 2) ? s1 : s0;
+        }
+        auto x4 = [&](float v) -> float {
+          int r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x104, 0xf, 0x5, false);
+          r = __builtin_amdgcn_update_dpp(r, __float_as_int(v), 0x114, 0xf, 0xa, false);
+          return __int_as_float(r);
+        };
+        const float t0 = w2[0] + x4(w2[0]), t1 = w2[1] + x4(w2[1]);
+        const float tot = (er & 1) ? t1 : t0;
+        if (tn0 != cs_tn0) {
+          if (cs_tn0 >= 0) atomicAdd((float*)p.bias + cs_tn0 + 64 * wc + 32 * (er >> 3) + 8 * ep + (er & 7), cs_run);
+          cs_run = 0.f; cs_tn0 = tn0;
+        }
+        cs_run += tot;
+      }
+    }
+    tix++;
+    if (!has_next) break;
+    T += G;
+    tm0 = nm0; tn0 = nn0; cA = nA; cB = nB;
+    has_next = T + G < nt;
+    tile_of(has_next ? T + G : T, nm0, nn0);
+    nA = (const unsigned char*)p.A + nm0 * lda2;
+    nB = (const unsigned char*)p.B + nn0 * ldb2;
+  }
+  if (EPI == EP_GATE_BITS && colsum && cs_tn0 >= 0) atomicAdd((float*)p.bias + cs_tn0 + 64 * wc + 32 * (lane >> 5) + 8 * (lane & 3) + ((lane >> 2) & 7), cs_run);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last tile's surplus prefetches land before the LDS is released
+#undef D_RD_A
+#undef D_RD_B
+#undef D_MFMA
+#undef D_BAR
+#undef D_LGKM0
+#undef D_VM
+}
+
+int g_gemm_d128 = 0;   // pero_set_option("gemm_d128", K / 64): stored products up to that many K-tiles take this kernel
+bool pero_launch_gemm_d128(const GemmP& p0, long long batch, bool ta, bool tb, bool out_f32, hipStream_t st) {
+  if (!g_gemm_d128 || batch != 1 || ta || tb || out_f32 || p0.M % D_BM || p0.N % D_BN || p0.K % E_BK || p0.K < 3 * E_BK) return false;
+  if (p0.alpha != 1.0f || (p0.flags & (PERO_GEMM_ATOMIC | PERO_GEMM_ACCUM | PERO_GEMM_ROWDOT)) || p0.resid) return false;
+  if (p0.lda >= (1LL << 22) || p0.ldb >= (1LL << 22) || p0.ldc >= (1LL << 22)) return false;
+  const bool relu = p0.flags & PERO_GEMM_RELU, bits = p0.flags & PERO_GEMM_RELU_BITS, cs = p0.flags & PERO_GEMM_COLSUM;
+  int epi;
+  if (bits) {
+    if (!p0.gate || (relu && cs) || p0.ldg >= (1LL << 22)) return false;
+    if (!relu && p0.bias && !cs) return false;   // (as gemm_bf16_e256: the gate epilogue has no input-bias path)
+    epi = relu ? EP_RELU_BITS : EP_GATE_BITS;
+  } else if (cs || p0.gate) return false;
+  else epi = relu ? EP_RELU : EP_PLAIN;
+  int num_cus = (pero_num_cus() / 8) * 8;
+  if (num_cus < 8) num_cus = 8;
+  GemmP p = p0;
+  p.kchunk = p.K;
+  const long long nt = (p.M / D_BM) * (p.N / D_BN);
+  if (nt < 2 * num_cus) return false;   // fewer tiles than workgroup places: the other kernels
+  const unsigned G = (unsigned)(2 * num_cus);
+  dim3 grid(G), block(256);
+#define LAUNCH_D(EP_)                                                                              \
+  do {                                                                                             \
+    PERO_LDS_ATTR((gemm_bf16_d128<EP_, 0>), D_LDS_BYTES);                                          \
+    hipLaunchKernelGGL((gemm_bf16_d128<EP_, 0>), grid, block, D_LDS_BYTES, st, p);                 \
+  } while (0)
+  switch (epi) {
+    case EP_RELU: LAUNCH_D(EP_RELU); break;
+    case EP_RELU_BITS: LAUNCH_D(EP_RELU_BITS); break;
+    case EP_GATE_BITS: LAUNCH_D(EP_GATE_BITS); break;
+    default: LAUNCH_D(EP_PLAIN); break;
+  }
+#undef LAUNCH_D
+  return true;
 }
 
 // =====================================================================================================================================
@@ -1745,6 +2158,7 @@ bool pero_launch_gemm_e256(const GemmP& p0, long long batch, int k_split, bool t
       case EP_ROWDOT: LAUNCH_E(false, false, EP_ROWDOT, 0); break;
       default:
         switch (var) {
+          case 1: LAUNCH_E(false, false, EP_PLAIN, 1); break;
           case 2: LAUNCH_E(false, false, EP_PLAIN, 2); break;
           case 4: LAUNCH_E(false, false, EP_PLAIN, 4); break;
           case 8: LAUNCH_E(false, false, EP_PLAIN, 8); break;

@@ -185,6 +185,61 @@ def test_strided_views_of_every_operand(e256):
     assert float((ca[:, 256:256 + N].float() - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
 
 
+@pytest.mark.parametrize("M,N,K", [(32768, 512, 192), (16384, 1024, 512), (65536, 2048, 512), (32768, 1536, 1024)])
+def test_two_workgroups_per_cu_tile_gives_the_bits_of_the_256x256_tile(e256, M, N, K):
+    """gemm_bf16_d128 (opt-in "gemm_d128": 256 x 128 tiles, four waves per workgroup, two independent workgroups per CU - round 4's measurement of
+    'the epilogue of one tile under the main loop of another', slower than gemm_bf16_e256 and therefore off): same K-tile and MFMA order per
+    output, so plain / bias / ReLU / bit-mask-out / bit-mask-gate products must agree bit for bit with the 256 x 256 tile; repeated launches give
+    identical bytes (its counted vmcnt waits); strided views of every operand."""
+    ops = e256
+    from pero_pretraining_amd._lib import call
+    torch.manual_seed(11)
+    xa = (torch.randn(M, K + 64, device="cuda") * 0.5).bfloat16()
+    wa = (torch.randn(N, K + 128, device="cuda") * 0.5).bfloat16()
+    x, w = xa[:, 64:], wa[:, :K]
+    bias = torch.randn(N, device="cuda")
+    gbits = torch.randint(0, 256, (M, N // 8), device="cuda", dtype=torch.uint8)
+
+    def run(kind):
+        ca = torch.full((M, N + 256), 7.0, device="cuda").bfloat16()
+        out = ca[:, 128:128 + N]
+        bits = torch.zeros(M, N // 8, device="cuda", dtype=torch.uint8)
+        if kind == "plain":
+            ops.gemm(x, w, out=out)
+        elif kind == "bias":
+            ops.gemm(x, w, out=out, bias=bias)
+        elif kind == "relu":
+            ops.gemm(x, w, out=out, bias=bias, relu=True)
+        elif kind == "relu_bits":
+            ops.gemm(x, w, out=out, bias=bias, relu=True, relu_bits=bits)
+        else:
+            ops.gemm(x, w, out=out, relu_bits=gbits)
+        assert torch.all(ca[:, :128] == 7.0) and torch.all(ca[:, 128 + N:] == 7.0)
+        return out.clone(), bits
+
+    try:
+        for kind in ("plain", "bias", "relu", "relu_bits", "gate"):
+            call("pero_set_option", b"gemm_d128", 0)
+            want, wbits = run(kind)
+            call("pero_set_option", b"gemm_d128", 64)
+            for _ in range(3):
+                got, gb = run(kind)
+                assert torch.equal(got, want), kind
+                assert torch.equal(gb, wbits), kind
+        # the column sums of the gated product (linear1's bias gradient): f32 atomics in both kernels, equal up to the order of the additions
+        cs0, cs1 = torch.zeros(N, device="cuda"), torch.zeros(N, device="cuda")
+        call("pero_set_option", b"gemm_d128", 0)
+        a = ops.gemm(x, w, relu_bits=gbits, colsum_into=cs0)
+        call("pero_set_option", b"gemm_d128", 64)
+        b = ops.gemm(x, w, relu_bits=gbits, colsum_into=cs1)
+        assert torch.equal(a, b)
+        ref = a.float().sum(0)
+        assert float((cs1 - ref).abs().max()) <= 1e-3 * float(ref.abs().max()) + 1e-2
+        assert float((cs1 - cs0).abs().max()) <= 1e-4 * float(ref.abs().max()) + 1e-2
+    finally:
+        call("pero_set_option", b"gemm_d128", 0)
+
+
 @pytest.mark.parametrize("M,K", [(1024, 192), (2176, 512), (65536, 1536), (131072, 2048)])
 def test_row_complete_tile_gives_the_bits_of_the_256x256_tile(e256, M, K):
     """gemm_bf16_n512 (opt-in "gemm_nw": one workgroup = 128 rows x all 512 columns, the tile the fused LayerNorm epilogues need): the same

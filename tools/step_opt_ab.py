@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""The B = 1024 masked step with a library option off / on, interleaved in one process (boxes differ by a few %).
+"""The masked step (2048 lines; PERO_AB_LINES) with a library option off / on, interleaved in one process (boxes differ by a few %).
 usage: python tools/step_opt_ab.py <option> [v0=0] [v1=1] [steps=8]"""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,7 +12,7 @@ steps = int(sys.argv[4]) if len(sys.argv) > 4 else 8
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
 model, opt_, sched, trainer = bench.build(dev, True)
-batches = bench.synthetic(0, 1024, dev)
+batches = bench.synthetic(0, int(os.environ.get("PERO_AB_LINES", "2048")), dev)
 def step(i):
     sched.update_learning_rate(i)
     b = batches[i % 2]
