@@ -373,6 +373,7 @@ extern int g_gemm_splitk_ws;          // gemm_e.hip
 extern int g_gemm_splitk_table;
 extern int g_gemm_nw;
 extern int g_gemm_d128;
+extern int g_gemm_e_walk;
 static int g_gemm_policy = 0;         // 0 = auto, 1 = 128x128x64 persistent kernel (this file), 4 = gemm_bf16_o128, 7 = gemm_bf16_r256, 20 = gemm_bf16_e256
 static int g_gemm_e256_min = 192;     // auto: stored products with at least this many 256x256 tiles take the eight-phase kernel (0 = never)
 static int g_gemm_e_splitk_min = 4;   // ... and split-K products (reduction >= 32768 rows) with at least this many output tiles
@@ -389,6 +390,7 @@ extern "C" int pero_set_option(const char* name, int value) {
   if (name && !strcmp(name, "splitk_table")) { g_gemm_splitk_table = value; return PERO_OK; }
   if (name && !strcmp(name, "gemm_nw")) { g_gemm_nw = value; return PERO_OK; }
   if (name && !strcmp(name, "gemm_d128")) { g_gemm_d128 = value; return PERO_OK; }
+  if (name && !strcmp(name, "gemm_e_walk")) { g_gemm_e_walk = value; return PERO_OK; }
   if (name && !strcmp(name, "gemm_e256_min")) { g_gemm_e256_min = value; return PERO_OK; }
   if (name && !strcmp(name, "gemm_e_splitk_min")) { g_gemm_e_splitk_min = value; return PERO_OK; }
   if (name && !strcmp(name, "splitk_xcd")) { g_pero_splitk_xcd = value; return PERO_OK; }

@@ -206,8 +206,18 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p, int ks) {
   const unsigned offA = elane_off<TA, true>(p.lda, tid), offB = elane_off<TB, false>(p.ldb, tid);
   const bool colsum = EPI == EP_GATE_BITS && (p.flags & PERO_GEMM_COLSUM);
 
+  // stored products: `ks` = N-tiles of one row panel a workgroup walks ONE AFTER THE OTHER (0 / 1: none - the ntn workgroups of an XCD that share a row panel
+  // run its ntn N-tiles side by side and all wait for the SAME bytes from HBM; `seq` > 1 leaves ntn / seq sharers per panel and seq x as many panels in flight)
+  const int ksq = ks & 15;
+  const bool inter = ks & 16;   // the side-by-side workgroups take ADJACENT N-tiles (n = r * sharers + j instead of j * seq + r)
+  const int seq = (EPI != EP_SPLITK && ksq > 1 && r8 == 0 && ntn % ksq == 0 && (G >> 3) % (ntn / ksq) == 0 && q8 % (((G >> 3) / (ntn / ksq)) * ntn) == 0) ? ksq : 1;
   auto tile_of = [&](int T, long long& tm0, long long& tn0) {
-    const int xcd = T & 7, loc = T >> 3;
+    const int xcd = T & 7;
+    int loc = T >> 3;
+    if (seq > 1) {
+      const int per = G >> 3, sh = ntn / seq, l = loc % per, k = loc / per;
+      loc = ((k / seq) * (per / sh) + l / sh) * ntn + (inter ? (k % seq) * sh + l % sh : (l % sh) * seq + k % seq);
+    }
     const int id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
     tm0 = (long long)(id / ntn) * E_BM;
     tn0 = (long long)(id % ntn) * E_BN;
@@ -2059,11 +2069,13 @@ long long pero_gemm_e256_splitk_ws_bytes(long long M, long long N, long long K, 
 // Qualifies: one problem (batch 1), bf16 operands; stored bf16 output (alpha == 1) or a split-K f32 product; M % 256 == N % 256 == K % 64 == 0, K >= 128.
 // ws / ws_bytes: the caller's workspace for the split-K partial tiles (pero_gemm's `workspace`); never allocated here.
 int g_gemm_e_var = 0;
+int g_gemm_e_walk = 1;   // pero_set_option("gemm_e_walk", 0): every stored product in the side-by-side order
 bool pero_launch_gemm_e256(const GemmP& p0, long long batch, int k_split, bool ta, bool tb, bool out_f32, hipStream_t st, int var, void* ws,
                            long long ws_bytes) {
   if (p0.M % E_BM || p0.N % E_BN || p0.K % E_BK || p0.K < 2 * E_BK || batch != 1) return false;
   if (var < 0) var = g_gemm_e_var;
   const int wg_cap = ((var >> 8) & 0xff) * 8;  // diagnostic: at most this many workgroups (bits 8-15 of the variant, in units of 8)
+  const int walk = (var >> 16) & 0x1f;         // stored products: N-tiles of a row panel per workgroup, one after the other (bits 16-19; see the kernel's tile_of)
   var &= 0xff;
   int ks = 0;
   if (p0.flags & PERO_GEMM_ATOMIC) {
@@ -2137,6 +2149,16 @@ bool pero_launch_gemm_e256(const GemmP& p0, long long batch, int k_split, bool t
   unsigned G = (unsigned)(nt < num_cus ? ((nt + 7) / 8) * 8 : num_cus);
   if (wg_cap && (unsigned)wg_cap < G) G = (unsigned)wg_cap;
   dim3 grid(G), block(512);
+  // Walk of the stored K <= 512 products (the kernel's tile_of): by default the ntn workgroups of an XCD that share a 256-row panel of A run its ntn N-tiles side
+  // by side and wait for the same bytes from HBM together.  With each workgroup taking `seq` N-tiles of its panel one after the other, seq x as many panels are in
+  // flight per XCD and the panel's later passes come from the caches: 524 288 x 2048 x 512 plain / ReLU 1 056 -> 1 010 us, bit-mask gate 1 086 -> 1 054, N = 1536
+  // 784 -> 772, N = 4096 2 117 -> 1 926 (seq 4 / 3; tools/e256_walk2.py).  NOT for the epilogue that writes the ReLU bit mask (its 32 bytes per row and tile are a
+  // quarter of a line: written rounds apart they cost more than the walk gains, 1 095 -> 1 147), not at K = 2048 (+- 1 %).  Same tiles, same bits.
+  ks = walk;
+  if (!walk && g_gemm_e_walk && p.K <= 512 && (epi == EP_PLAIN || epi == EP_RELU || epi == EP_GATE_BITS) && nt >= 2LL * G) {
+    const long long ntn = p.N / E_BN;
+    ks = (ntn >= 8 && ntn % 4 == 0) ? 4 : (ntn >= 6 && ntn % 3 == 0) ? 3 : 0;
+  }
   if (epi == EP_ROWDOT) {  // the two waves of a 128-column block add into it: cleared first (hipMemsetAsync's fill kernel took 27 us for these 4 MB)
     const long long n = p.M * (p.N >> 7);
     if (n % 4 == 0 && aligned16(p.bias))

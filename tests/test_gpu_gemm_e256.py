@@ -185,6 +185,50 @@ def test_strided_views_of_every_operand(e256):
     assert float((ca[:, 256:256 + N].float() - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
 
 
+@pytest.mark.parametrize("M,N,K", [(16384, 2048, 512), (32768, 1536, 512), (16384, 4096, 256), (65536, 2048, 512)])
+def test_sequential_walk_of_a_row_panel_gives_the_same_bits(e256, M, N, K):
+    """Stored K <= 512 products walk the N-tiles of a 256-row panel partly one after the other (round 4, pero_launch_gemm_e256: `gemm_e_walk`, default on for the
+    plain / ReLU / bit-mask-gate epilogues): a different tile -> workgroup order and nothing else, so the output must equal the side-by-side order's bit for bit,
+    every tile written exactly once (a guard band around the output view stays untouched), column sums equal up to the order of the atomics."""
+    ops = e256
+    from pero_pretraining_amd._lib import call
+    torch.manual_seed(12)
+    x = (torch.randn(M, K, device="cuda") * 0.5).bfloat16()
+    w = (torch.randn(N, K, device="cuda") * 0.5).bfloat16()
+    bias = torch.randn(N, device="cuda")
+    gbits = torch.randint(0, 256, (M, N // 8), device="cuda", dtype=torch.uint8)
+
+    def run(kind, walk):
+        call("pero_set_option", b"gemm_e_walk", walk)
+        ca = torch.full((M, N + 256), 7.0, device="cuda").bfloat16()
+        out = ca[:, 128:128 + N]
+        cs = torch.zeros(N, device="cuda")
+        if kind == "plain":
+            ops.gemm(x, w, out=out)
+        elif kind == "bias":
+            ops.gemm(x, w, out=out, bias=bias)
+        elif kind == "relu":
+            ops.gemm(x, w, out=out, bias=bias, relu=True)
+        elif kind == "gate":
+            ops.gemm(x, w, out=out, relu_bits=gbits)
+        else:
+            ops.gemm(x, w, out=out, relu_bits=gbits, colsum_into=cs)
+        assert torch.all(ca[:, :128] == 7.0) and torch.all(ca[:, 128 + N:] == 7.0)
+        return out.clone(), cs
+
+    try:
+        for kind in ("plain", "bias", "relu", "gate", "gate_colsum"):
+            want, wcs = run(kind, 0)
+            for _ in range(2):
+                got, gcs = run(kind, 1)
+                assert torch.equal(got, want), kind
+                assert float((gcs - wcs).abs().max()) <= 1e-4 * float(wcs.abs().max()) + 1e-2, kind
+        ref = x[:512].float() @ w.float().t()
+        assert float((run("plain", 1)[0][:512].float() - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
+    finally:
+        call("pero_set_option", b"gemm_e_walk", 1)
+
+
 @pytest.mark.parametrize("M,N,K", [(32768, 512, 192), (16384, 1024, 512), (65536, 2048, 512), (32768, 1536, 1024)])
 def test_two_workgroups_per_cu_tile_gives_the_bits_of_the_256x256_tile(e256, M, N, K):
     """gemm_bf16_d128 (opt-in "gemm_d128": 256 x 128 tiles, four waves per workgroup, two independent workgroups per CU - round 4's measurement of

@@ -21,7 +21,7 @@ def show(tag, ph):   # ph: [G][2][32] int64
         print(f"{tag} wave {4 * w}: " + " | ".join(parts) + f" | K-tile {tot:.0f} cyc", flush=True)
 
 
-M = 65536
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 for (N, K) in [(2048, 512), (2048, 2048)]:
     x = (torch.randn(M, K, device="cuda") * 0.5).bfloat16()
     w = (torch.randn(N, K, device="cuda") * 0.5).bfloat16()
