@@ -316,9 +316,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p, int ks) {
   // one; a workgroup's last tile "prefetches" its own first K-tiles again: the stream keeps its shape, no branches)
   const EStep<TA, 64> sa(p.lda);
   const EStep<TB, 32> sb(p.ldb);
-  const unsigned char* cA = (const unsigned char*)A + tm0 * sa.tile + (kbeg / E_BK) * sa.ktile;
+  // (ks & 32, timing probe for stored products: every tile reads its A rows from the first 4096 rows - always in L2 -, results wrong by design)
+  const long long amask = (EPI != EP_SPLITK && (ks & 32)) ? 4095 : -1LL;
+  const unsigned char* cA = (const unsigned char*)A + (tm0 & amask) * sa.tile + (kbeg / E_BK) * sa.ktile;
   const unsigned char* cB = (const unsigned char*)B + tn0 * sb.tile + (kbeg / E_BK) * sb.ktile;
-  const unsigned char* nA = (const unsigned char*)A + nm0 * sa.tile;
+  const unsigned char* nA = (const unsigned char*)A + (nm0 & amask) * sa.tile;
   const unsigned char* nB = (const unsigned char*)B + nn0 * sb.tile;
   auto issue = [&](int u, int which, unsigned char* ktbase) {
     if (EPI == EP_SPLITK && u >= nk) return;  // one work item: nothing follows (the ring is the epilogue's staging area)
@@ -819,7 +821,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p, int ks) {
     tm0 = nm0; tn0 = nn0; cA = nA; cB = nB;
     has_next = T + G < nt;
     tile_of(has_next ? T + G : T, nm0, nn0);
-    nA = (const unsigned char*)A + nm0 * sa.tile;
+    nA = (const unsigned char*)A + (nm0 & amask) * sa.tile;
     nB = (const unsigned char*)B + nn0 * sb.tile;
     if (!(VAR & 16) && wr == 1) { E_BAR(); }  // the stagger again
   }
@@ -2075,7 +2077,7 @@ bool pero_launch_gemm_e256(const GemmP& p0, long long batch, int k_split, bool t
   if (p0.M % E_BM || p0.N % E_BN || p0.K % E_BK || p0.K < 2 * E_BK || batch != 1) return false;
   if (var < 0) var = g_gemm_e_var;
   const int wg_cap = ((var >> 8) & 0xff) * 8;  // diagnostic: at most this many workgroups (bits 8-15 of the variant, in units of 8)
-  const int walk = (var >> 16) & 0x1f;         // stored products: N-tiles of a row panel per workgroup, one after the other (bits 16-19; see the kernel's tile_of)
+  const int walk = (var >> 16) & 0x3f;         // stored products (bit 5: the A-rows-from-L2 timing probe): N-tiles of a row panel per workgroup, one after the other (bits 16-19; see the kernel's tile_of)
   var &= 0xff;
   int ks = 0;
   if (p0.flags & PERO_GEMM_ATOMIC) {
@@ -2155,9 +2157,9 @@ bool pero_launch_gemm_e256(const GemmP& p0, long long batch, int k_split, bool t
   // 784 -> 772, N = 4096 2 117 -> 1 926 (seq 4 / 3; tools/e256_walk2.py).  NOT for the epilogue that writes the ReLU bit mask (its 32 bytes per row and tile are a
   // quarter of a line: written rounds apart they cost more than the walk gains, 1 095 -> 1 147), not at K = 2048 (+- 1 %).  Same tiles, same bits.
   ks = walk;
-  if (!walk && g_gemm_e_walk && p.K <= 512 && (epi == EP_PLAIN || epi == EP_RELU || epi == EP_GATE_BITS) && nt >= 2LL * G) {
+  if (!(walk & 31) && g_gemm_e_walk && p.K <= 512 && (epi == EP_PLAIN || epi == EP_RELU || epi == EP_GATE_BITS) && nt >= 2LL * G) {
     const long long ntn = p.N / E_BN;
-    ks = (ntn >= 8 && ntn % 4 == 0) ? 4 : (ntn >= 6 && ntn % 3 == 0) ? 3 : 0;
+    ks = (walk & 32) | ((ntn >= 8 && ntn % 4 == 0) ? 4 : (ntn >= 6 && ntn % 3 == 0) ? 3 : 0);
   }
   if (epi == EP_ROWDOT) {  // the two waves of a 128-column block add into it: cleared first (hipMemsetAsync's fill kernel took 27 us for these 4 MB)
     const long long n = p.M * (p.N >> 7);
