@@ -114,6 +114,11 @@ def lib():
             fn = getattr(h, name)
             fn.restype = ctypes.c_int
             fn.argtypes = args
+        # PERO_OPTIONS="name=value,name=value": pero_set_option knobs for a whole process (A/B runs of a tool or of bench.py under a profiler); unknown names raise
+        for item in filter(None, os.environ.get("PERO_OPTIONS", "").split(",")):
+            name, _, value = item.partition("=")
+            if h.pero_set_option(name.strip().encode(), int(value)) != 0:
+                raise PeroHipError(f"PERO_OPTIONS: {h.pero_last_error().decode()}")
         _lib = h
     return _lib
 
