@@ -54,6 +54,10 @@ extern "C" {
                                    PERO_GEMM_RELU `gate` is an OUTPUT: bit = (stored C[m][n] > 0); without it `gate` is that mask
                                    as INPUT and replaces the bf16 gate matrix (1/16 of its bytes).  bf16 C, batch 1, the 256-row
                                    tile kernels only (M % 256 == 0, N % 128 == 0, K % 32 == 0): anything else is PERO_E_INVALID */
+#define PERO_GEMM_MASK_TILED 16384 /* with PERO_GEMM_RELU_BITS, N % 256 == 0: the bit mask is stored per 256-column block - bit (n & 7) of byte
+                                   gate[(n / 256) * M * 32 + m * 32 + (n % 256) / 8] (ldg ignored; the same M * N / 8 bytes) - so that a 256 x 256
+                                   tile's mask is 8 KiB of contiguous bytes (whole lines) instead of a quarter of a line per row.  Producer and consumer
+                                   of a mask must agree. */
 #define PERO_GEMM_COLSUM 1024   /* `bias` is an OUTPUT (f32 [N], accumulated atomically): column sums over the M rows of the
                                  * stored result - the bias gradient of the Linear whose output gradient this product
                                  * writes (replaces a separate pero_colsum pass over C).  No input bias in this mode. */

@@ -15,6 +15,7 @@ LN_BWD_BLOCKS = 512
 GEMM_RELU, GEMM_ATOMIC, GEMM_ACCUM, GEMM_TRANS_A, GEMM_TRANS_B, GEMM_FORCE_GENERIC = 1, 2, 4, 8, 16, 32
 GEMM_ROWDOT = 4096   # `gate` = second matrix, `bias` = f32 [M][N/128] output of the 128-column-block row dots of the stored result
 GEMM_RELU_BITS = 8192
+GEMM_MASK_TILED = 16384
 GEMM_COLSUM = 1024  # `bias` is an OUTPUT: column sums of the stored result (bias gradient of the upstream Linear)
 GEMM_TILE_V = 512  # prefer the 256x256x64 kernel: products that have the GPU to themselves (forward pass)
 GEMM_TILE128, GEMM_TILE256 = 64, 128

@@ -518,6 +518,7 @@ static int gemm_dispatch(const void* A, const void* B, void* C, const float* bia
               (!gate || (flags & PERO_GEMM_RELU_BITS) || (ldg % 8 == 0 && aligned16(gate))) && (!(residual || gate) || out_dtype == PERO_BF16 || true);
   if (fast && g_gemm_policy == 1) { flags |= PERO_GEMM_TILE128; p.flags = flags; pc.flags = flags | cs_bits; }
   const bool force128 = flags & PERO_GEMM_TILE128, force256 = flags & PERO_GEMM_TILE256;
+  PERO_REQUIRE(!(flags & PERO_GEMM_MASK_TILED) || ((flags & PERO_GEMM_RELU_BITS) && N % 256 == 0), "pero_gemm: PERO_GEMM_MASK_TILED needs PERO_GEMM_RELU_BITS and N %% 256 == 0");
   if (flags & PERO_GEMM_RELU_BITS) {
     // bit-mask ReLU gate: only the e256 / r256 epilogues read or write it
     PERO_REQUIRE(fast && gate && batch == 1 && out_dtype == PERO_BF16 && !ta && !(flags & PERO_GEMM_ATOMIC) && !force128 && M % 256 == 0 &&

@@ -394,7 +394,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p, int ks) {
   const int tsrc = 4 * (er + 16 * (((ep & 1) << 1) | (ep >> 1)));                  // ds_bpermute address: the lane that holds (row er, piece ep)
   const unsigned cvo = (unsigned)(((128 * wr + er) * p.ldc + 64 * wc + 8 * ep) * 2);   // C
   const unsigned gvo = (unsigned)(((128 * wr + er) * (EPI == EP_RESID ? p.ldr : p.ldg) + 64 * wc + 8 * ep) * 2);  // residual / row-dot matrix
-  const unsigned mvo = (unsigned)((128 * wr + er) * p.ldg + 8 * wc);               // bit mask: 8 bytes per row and wave
+  // bit mask (EP_RELU_BITS out, EP_GATE_BITS in): 8 bytes per row and wave; row pitch ldg, or - PERO_GEMM_MASK_TILED - 32 bytes inside the N-tile's own M x 32 plane
+  const bool mtiled = (EPI == EP_RELU_BITS || EPI == EP_GATE_BITS) && (p.flags & PERO_GEMM_MASK_TILED);
+  const long long mld = mtiled ? 32 : p.ldg;
+  auto mask_base = [&](long long tm, long long tn) -> const unsigned char* {
+    return (const unsigned char*)p.gate + (mtiled ? (tn >> 8) * p.M * 32 + tm * 32 : tm * p.ldg + (tn >> 3));
+  };
+  const unsigned mvo = (unsigned)((128 * wr + er) * mld + 8 * wc);
   auto lane_t = [&](const unsigned x) -> unsigned { return (unsigned)__builtin_amdgcn_ds_bpermute(tsrc, (int)x); };
   (void)cq; (void)tsrc;
   // The same transpose through LDS memory (E_XCHG_LDS): a unit is written as the lanes hold it (one ds_write_b128: row li, piece cq)
@@ -432,10 +438,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p, int ks) {
     issue_bias(tn0);  // this tile's bias row for its epilogue: part of the stream (older than everything a later wait counts)
 
     // side-input descriptor of this tile
-    const int spitch = (int)(EPI == EP_RESID ? p.ldr * 2 : EPI == EP_ROWDOT ? p.ldg * 2 : p.ldg);  // bytes per row
+    const int spitch = (int)(EPI == EP_RESID ? p.ldr * 2 : EPI == EP_ROWDOT ? p.ldg * 2 : mld);  // bytes per row
     const ei4v srs = ersrc(EPI == EP_RESID ? (const void*)((const bf16raw*)p.resid + tm0 * p.ldr + tn0)
                            : EPI == EP_ROWDOT ? (const void*)((const bf16raw*)p.gate + tm0 * p.ldg + tn0)
-                           : (const void*)((const unsigned char*)p.gate + tm0 * p.ldg + (tn0 >> 3)),
+                           : (const void*)mask_base(tm0, tn0),
                            (unsigned)(256 * spitch));
 
     // one K-tile; LAST = the tile's last one (peeled: the side loads of the epilogue start in its phase 4 and their registers
@@ -752,11 +758,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_e256(GemmP p, int ks) {
               mL |= (unsigned)__builtin_amdgcn_mov_dpp((int)mL, 0x4E, 0xf, 0xf, false);  // quad_perm [2,3,0,1]
               mH |= (unsigned)__builtin_amdgcn_mov_dpp((int)mH, 0x4E, 0xf, 0xf, false);
               const eu2v mo = {mL, mH};
-              const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc((unsigned char*)p.gate + tm0 * p.ldg + (tn0 >> 3), 0, (int)(256 * p.ldg), 0x00020000);
+              const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc((unsigned char*)mask_base(tm0, tn0), 0, (int)(256 * mld), 0x00020000);
               // all four store them (same address, same data): one instruction, no branch (storing from the quad's first lane only
               // measured no faster)
               if (E_ABL & 1) asm volatile("" :: "v"(mo[0]), "v"(mo[1]));
-              else __builtin_amdgcn_raw_buffer_store_b64(mo, mrs, mvo, (64 * ha + 16 * i) * (int)p.ldg, 0);
+              else __builtin_amdgcn_raw_buffer_store_b64(mo, mrs, mvo, (64 * ha + 16 * i) * (int)mld, 0);
             }
             if (EPI == EP_ROWDOT) {
               // sum over the four lanes of a row (one quad), then its first lane adds into [m][n / 128] (two waves per 128-column block)
@@ -1218,7 +1224,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_d128(GemmP p) {
 int g_gemm_d128 = 0;   // pero_set_option("gemm_d128", K / 64): stored products up to that many K-tiles take this kernel
 bool pero_launch_gemm_d128(const GemmP& p0, long long batch, bool ta, bool tb, bool out_f32, hipStream_t st) {
   if (!g_gemm_d128 || batch != 1 || ta || tb || out_f32 || p0.M % D_BM || p0.N % D_BN || p0.K % E_BK || p0.K < 3 * E_BK) return false;
-  if (p0.alpha != 1.0f || (p0.flags & (PERO_GEMM_ATOMIC | PERO_GEMM_ACCUM | PERO_GEMM_ROWDOT)) || p0.resid) return false;
+  if (p0.alpha != 1.0f || (p0.flags & (PERO_GEMM_ATOMIC | PERO_GEMM_ACCUM | PERO_GEMM_ROWDOT | PERO_GEMM_MASK_TILED)) || p0.resid) return false;
   if (p0.lda >= (1LL << 22) || p0.ldb >= (1LL << 22) || p0.ldc >= (1LL << 22)) return false;
   const bool relu = p0.flags & PERO_GEMM_RELU, bits = p0.flags & PERO_GEMM_RELU_BITS, cs = p0.flags & PERO_GEMM_COLSUM;
   int epi;
@@ -2154,10 +2160,10 @@ bool pero_launch_gemm_e256(const GemmP& p0, long long batch, int k_split, bool t
   // Walk of the stored K <= 512 products (the kernel's tile_of): by default the ntn workgroups of an XCD that share a 256-row panel of A run its ntn N-tiles side
   // by side and wait for the same bytes from HBM together.  With each workgroup taking `seq` N-tiles of its panel one after the other, seq x as many panels are in
   // flight per XCD and the panel's later passes come from the caches: 524 288 x 2048 x 512 plain / ReLU 1 056 -> 1 010 us, bit-mask gate 1 086 -> 1 054, N = 1536
-  // 784 -> 772, N = 4096 2 117 -> 1 926 (seq 4 / 3; tools/e256_walk2.py).  NOT for the epilogue that writes the ReLU bit mask (its 32 bytes per row and tile are a
-  // quarter of a line: written rounds apart they cost more than the walk gains, 1 095 -> 1 147), not at K = 2048 (+- 1 %).  Same tiles, same bits.
+  // 784 -> 772, N = 4096 2 117 -> 1 926 (seq 4 / 3; tools/e256_walk2.py).  NOT for the epilogue that writes the ReLU bit mask in ROWS (its 32 bytes per row and tile are a
+  // quarter of a line: written rounds apart they cost more than the walk gains, 1 095 -> 1 147; with PERO_GEMM_MASK_TILED a tile's mask is whole lines), not at K = 2048 (+- 1 %).  Same tiles, same bits.
   ks = walk;
-  if (!(walk & 31) && g_gemm_e_walk && p.K <= 512 && (epi == EP_PLAIN || epi == EP_RELU || epi == EP_GATE_BITS) && nt >= 2LL * G) {
+  if (!(walk & 31) && g_gemm_e_walk && p.K <= 512 && (epi == EP_PLAIN || epi == EP_RELU || epi == EP_GATE_BITS || (epi == EP_RELU_BITS && (p.flags & PERO_GEMM_MASK_TILED))) && nt >= 2LL * G) {
     const long long ntn = p.N / E_BN;
     ks = (walk & 32) | ((ntn >= 8 && ntn % 4 == 0) ? 4 : (ntn >= 6 && ntn % 3 == 0) ? 3 : 0);
   }

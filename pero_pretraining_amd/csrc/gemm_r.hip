@@ -230,7 +230,8 @@ __global__ __launch_bounds__(512, 4) void gemm_bf16_r256(GemmP p, int ks_xcd) {
         if ((tid & 15) == 0) ((float*)p.bias)[grow * (p.N >> 7) + (tn0 >> 7)] = dot;
       } else if (p.gate && (p.flags & PERO_GEMM_RELU_BITS)) {
         // the ReLU gate as bits: one byte per thread (its 8 columns) and row
-        unsigned char* gb = (unsigned char*)p.gate + grow * p.ldg + ((tn0 + c8) >> 3);
+        unsigned char* gb = (p.flags & PERO_GEMM_MASK_TILED) ? (unsigned char*)p.gate + ((tn0 + c8) >> 8) * p.M * 32 + grow * 32 + (((tn0 + c8) & 255) >> 3)
+                                                             : (unsigned char*)p.gate + grow * p.ldg + ((tn0 + c8) >> 3);
         if (p.flags & PERO_GEMM_RELU) {
           unsigned m = 0;
 #pragma unroll

@@ -44,6 +44,14 @@ RELU_GATE_BITS = True    # linear1's ReLU leaves a bit mask (free in its epilogu
                          # tile's bytes ahead of the staging barriers, instead of eight dependent 16-byte gate rows: step -0.7 %
 
 
+RELU_BITS_TILED = True   # the mask per 256-column block ([N/256][M][32 B]) when N % 256 == 0: a tile's mask is whole cache lines, and linear1's product may walk its
+                         # tiles like the other K = 512 products (ops.gemm bits_tiled; csrc/gemm_e.hip pero_launch_gemm_e256)
+
+
+def bits_tiled(n):
+    return RELU_BITS_TILED and n % 256 == 0
+
+
 def relu_bits_ok(m, n, k, dtype):
     """Shapes for which the ReLU of a Linear can leave its gate as a bit mask (PERO_GEMM_RELU_BITS: the 256-row tile kernels)."""
     return RELU_GATE_BITS and dtype == torch.bfloat16 and m % 256 == 0 and n % 128 == 0 and k % 32 == 0
@@ -51,7 +59,7 @@ def relu_bits_ok(m, n, k, dtype):
 
 def linear_fwd(x, w, b, dtype, residual=None, relu=False, out_dtype=None, relu_bits=None):
     return ops.gemm(x, lowp.weight(w, dtype), relu_bits=relu_bits, bias=None if b is None else b.detach(), residual=residual, relu=relu,
-                    out_dtype=out_dtype, extra_flags=FWD_TILE_FLAGS)
+                    out_dtype=out_dtype, extra_flags=FWD_TILE_FLAGS, bits_tiled=relu_bits is not None and bits_tiled(w.shape[0]))
 
 
 FUSE_ROWDOT = True     # attention backward's D = rowsum(dO * O) from the epilogue of the out-projection's dX product
@@ -143,7 +151,8 @@ def linear_bwd(dy, x, w, b, dtype, need_dx=True, gate=None, residual=None, bias_
     if DX_ON_WT and dtype == torch.bfloat16:
         # dX = dY (W^T)^T on a transposed bf16 weight copy: both operands K-contiguous, 256x256x64 tiles
         return ops.gemm(dy, lowp.weight_t(w), residual=residual, gate=None if gate_bits is not None else gate,
-                        relu_bits=gate_bits, colsum_into=dx_colsum_into, rowdot=dx_rowdot, extra_flags=DX_TILE_FLAGS)
+                        relu_bits=gate_bits, colsum_into=dx_colsum_into, rowdot=dx_rowdot, extra_flags=DX_TILE_FLAGS,
+                        bits_tiled=gate_bits is not None and bits_tiled(w.shape[1]))
     if gate_bits is not None:
         raise RuntimeError("linear_bwd: a bit-mask gate needs the bf16 transposed-weight path")
     return ops.gemm(dy, lowp.weight(w, dtype).view(w.shape[0], -1), trans_b=True, residual=residual, gate=gate,

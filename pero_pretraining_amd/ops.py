@@ -6,7 +6,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import (GEMM_ACCUM, GEMM_ATOMIC, GEMM_COLSUM, GEMM_FORCE_GENERIC, GEMM_ROWDOT, GEMM_RELU, GEMM_RELU_BITS, GEMM_TRANS_A, GEMM_TRANS_B,
+from ._lib import (GEMM_ACCUM, GEMM_ATOMIC, GEMM_COLSUM, GEMM_FORCE_GENERIC, GEMM_MASK_TILED, GEMM_ROWDOT, GEMM_RELU, GEMM_RELU_BITS, GEMM_TRANS_A, GEMM_TRANS_B,
                    PERO_BF16, PERO_F32, call)
 
 
@@ -88,13 +88,14 @@ def gemm_raw(A, B, C, M, N, K, lda, ldb, ldc, *, bias=None, residual=None, gate=
 
 def gemm(a, b, out=None, *, bias=None, residual=None, gate=None, trans_a=False, trans_b=False, relu=False,
          alpha=1.0, out_dtype=None, atomic=False, accum=False, k_split=1, force_generic=False, extra_flags=0,
-         colsum_into=None, rowdot=None, relu_bits=None):
+         colsum_into=None, rowdot=None, relu_bits=None, bits_tiled=False):
     """out[M,N] = alpha * op(a) @ op(b)^T ...   a: [M,K] ([K,M] if trans_a); b: [N,K] ([K,N] if trans_b).
     Row-strided 2-D views are fine (unit stride in the last dim).  colsum_into (f32 [N]): the column sums of the stored
     result are accumulated into it (PERO_GEMM_COLSUM; no input bias in that mode).  rowdot = (y, out): out (f32 [M][N/128])
     receives, per 128-column block, the row dots of the stored bf16 result with y (bf16 [M][N]) - PERO_GEMM_ROWDOT.
     relu_bits (uint8 [M][N/8]): with relu=True it RECEIVES the bit mask (stored result > 0); otherwise it is applied as the
-    ReLU gate in place of a bf16 gate matrix - PERO_GEMM_RELU_BITS."""
+    ReLU gate in place of a bf16 gate matrix - PERO_GEMM_RELU_BITS.  bits_tiled: the mask is laid out per 256-column block ([N/256][M][32 bytes],
+    PERO_GEMM_MASK_TILED; N % 256 == 0, relu_bits contiguous) - producer and consumer must pass the same value."""
     assert a.dim() == 2 and b.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1
     M, K = (a.shape[1], a.shape[0]) if trans_a else a.shape
     N, Kb = (b.shape[1], b.shape[0]) if trans_b else b.shape
@@ -110,6 +111,9 @@ def gemm(a, b, out=None, *, bias=None, residual=None, gate=None, trans_a=False, 
     if relu_bits is not None:
         assert gate is None and relu_bits.dtype == torch.uint8 and relu_bits.shape == (M, N // 8) and relu_bits.stride(1) == 1
         gate, flags = relu_bits, flags | GEMM_RELU_BITS
+        if bits_tiled:
+            assert N % 256 == 0 and relu_bits.is_contiguous()
+            flags |= GEMM_MASK_TILED
     if rowdot is not None:
         y, dots = rowdot
         assert bias is None and gate is None and N % 128 == 0 and y.shape == (M, N) and y.stride(1) == 1

@@ -185,6 +185,46 @@ def test_strided_views_of_every_operand(e256):
     assert float((ca[:, 256:256 + N].float() - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
 
 
+def _tile_mask(bits, M, N):
+    """row-major [M][N/8] -> PERO_GEMM_MASK_TILED [N/256][M][32]"""
+    return bits.view(M, N // 256, 32).permute(1, 0, 2).contiguous().view(M, N // 8)
+
+
+@pytest.mark.parametrize("M,N,K,policy", [(65536, 2048, 512, 20), (16384, 2048, 512, 20), (16384, 1024, 256, 20), (1024, 2048, 512, 7), (512, 512, 128, 7)])
+def test_bit_mask_per_256_column_block_is_the_row_mask_rearranged(M, N, K, policy):
+    """PERO_GEMM_MASK_TILED (round 4): the ReLU bit mask stored per 256-column block, [N/256][M][32 bytes], so that a tile's mask is whole cache lines.  Producer
+    (ReLU + bias, mask out) and consumer (mask as the gate, with the column sums) on both 256-row tile kernels (policy 20: gemm_bf16_e256 - with its sequential
+    walk at K <= 512 -, 7: gemm_bf16_r256): C bit-identical to the row-major form, the mask the same bits in the other order."""
+    from pero_pretraining_amd import _lib, ops
+    L = _lib.lib()
+    torch.manual_seed(13)
+    x = (torch.randn(M, K, device="cuda") * 0.5).bfloat16()
+    w = (torch.randn(N, K, device="cuda") * 0.5).bfloat16()
+    bias = torch.randn(N, device="cuda")
+    L.pero_set_option(b"gemm_policy", policy)
+    try:
+        b0 = torch.zeros(M, N // 8, device="cuda", dtype=torch.uint8)
+        b1 = torch.zeros(M, N // 8, device="cuda", dtype=torch.uint8)
+        c0 = ops.gemm(x, w, bias=bias, relu=True, relu_bits=b0)
+        c1 = ops.gemm(x, w, bias=bias, relu=True, relu_bits=b1, bits_tiled=True)
+        assert torch.equal(c0, c1)
+        assert torch.equal(_tile_mask(b0, M, N), b1)
+        want = torch.zeros_like(b0)
+        pos = (c0 > 0).view(M, N // 8, 8).to(torch.int32)
+        want = (pos * (2 ** torch.arange(8, device="cuda", dtype=torch.int32))).sum(-1).to(torch.uint8)
+        assert torch.equal(b0, want)
+        g = torch.randint(0, 256, (M, N // 8), device="cuda", dtype=torch.uint8)
+        cs0, cs1 = torch.zeros(N, device="cuda"), torch.zeros(N, device="cuda")
+        d0 = ops.gemm(x, w, relu_bits=g, colsum_into=cs0)
+        d1 = ops.gemm(x, w, relu_bits=_tile_mask(g, M, N), colsum_into=cs1, bits_tiled=True)
+        assert torch.equal(d0, d1)
+        assert float((cs0 - cs1).abs().max()) <= 1e-4 * float(cs0.abs().max()) + 1e-2
+        for _ in range(3):
+            assert torch.equal(ops.gemm(x, w, relu_bits=_tile_mask(g, M, N), bits_tiled=True), d0)
+    finally:
+        L.pero_set_option(b"gemm_policy", 0)
+
+
 @pytest.mark.parametrize("M,N,K", [(16384, 2048, 512), (32768, 1536, 512), (16384, 4096, 256), (65536, 2048, 512)])
 def test_sequential_walk_of_a_row_panel_gives_the_same_bits(e256, M, N, K):
     """Stored K <= 512 products walk the N-tiles of a 256-row panel partly one after the other (round 4, pero_launch_gemm_e256: `gemm_e_walk`, default on for the

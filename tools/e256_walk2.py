@@ -18,7 +18,7 @@ def bench(fn, iters=10):
     return sorted(ts)[2]
 cases = []
 x512 = (torch.randn(M, 512, device="cuda") * 0.5).bfloat16()
-for name, N, K, seqs in (("linear1 relu+bits", 2048, 512, (0, 2, 4, 18, 20)), ("linear1 relu", 2048, 512, (0, 4, 20)), ("linear2 dX gate+colsum", 2048, 512, (0, 4, 20)), ("linear2 dX gate", 2048, 512, (0, 4, 20)), ("in_proj bias", 1536, 512, (0, 3, 19)),
+for name, N, K, seqs in (("linear1 relu+bits", 2048, 512, (0, 2, 4, 18, 20)), ("linear1 relu+bits tiled", 2048, 512, (0, 2, 4)), ("linear2 dX gate+colsum tiled", 2048, 512, (0, 4)), ("linear1 relu", 2048, 512, (0, 4, 20)), ("linear2 dX gate+colsum", 2048, 512, (0, 4, 20)), ("linear2 dX gate", 2048, 512, (0, 4, 20)), ("in_proj bias", 1536, 512, (0, 3, 19)),
                          ("plain", 2048, 512, (0, 4, 20))):
     w = (torch.randn(N, K, device="cuda") * 0.05).bfloat16()
     bias = torch.randn(N, device="cuda")
@@ -30,6 +30,8 @@ for name, N, K, seqs in (("linear1 relu+bits", 2048, 512, (0, 2, 4, 18, 20)), ("
     dots = torch.zeros(M * (N // 128), device="cuda") if y is not None else None
     if name == "linear1 relu": fn = lambda: ops.gemm(x512, w, out, bias=bias, relu=True)
     elif name == "linear2 dX gate": fn = lambda: ops.gemm(x512, w, out, relu_bits=gbits)
+    elif name == "linear1 relu+bits tiled": fn = lambda: ops.gemm(x512, w, out, bias=bias, relu=True, relu_bits=bits, bits_tiled=True)
+    elif name == "linear2 dX gate+colsum tiled": fn = lambda: ops.gemm(x512, w, out, relu_bits=gbits, colsum_into=cs, bits_tiled=True)
     elif "relu" in name: fn = lambda: ops.gemm(x512, w, out, bias=bias, relu=True, relu_bits=bits)
     elif "gate" in name: fn = lambda: ops.gemm(x512, w, out, relu_bits=gbits, colsum_into=cs)
     elif "rowdot" in name: fn = lambda: ops.gemm(x512, w, out, rowdot=(y, dots))
@@ -40,10 +42,11 @@ for name, N, K, seqs in (("linear1 relu+bits", 2048, 512, (0, 2, 4, 18, 20)), ("
     line = []
     for rep in range(2):
         for seq in seqs:
+            _lib.call("pero_set_option", b"gemm_e_walk", 0)
             _lib.call("pero_set_option", b"gemm_e_var", seq << 16)
             t = bench(fn)
             if ref is None: ref = out.clone()
             line.append(f"seq {seq}: {t:.0f} us ({fl / t / 1e6:.0f}){'' if torch.equal(out, ref) else ' DIFFERENT'}")
     print(f"{name} [{N} x {K}]: " + " | ".join(line), flush=True)
     del w, out, bits, gbits, y, dots
-_lib.call("pero_set_option", b"gemm_e_var", 0)
+_lib.call("pero_set_option", b"gemm_e_var", 0); _lib.call("pero_set_option", b"gemm_e_walk", 1)
