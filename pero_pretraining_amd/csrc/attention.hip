@@ -1026,11 +1026,30 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv2_k(const bf16raw* qkv, co
 // (FETCH_SIZE of the backward at 256 lines: 534 MB as two launches, 308 MB paired, 267 MB = each row once; 789 -> 740 us at 1024 lines).
 template <bool PIPE>
 __global__ __launch_bounds__(256, 2) void attn_bwd_pair_k(const bf16raw* qkv, const bf16raw* dout, const float* lse2, float* dvec,
-                                                          bf16raw* dqkv, float* dbias, int S, int nh, float c, float scale) {
+                                                          bf16raw* dqkv, float* dbias, int S, int nh, float c, float scale, int order) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int nb = S >> 7;
   int lh, blk;
   attn_block_map(blockIdx.x, 2 * nb, gridDim.x / (2 * nb), lh, blk);
+  {   // Dispatch order inside an XCD (pero_set_option("attn_order", n); default 4): chunks of four units whose dK / dV blocks (the longer ones) go out ahead of their dQ blocks -
+      // 1 432 -> 1 397 us per 2048 lines (medians of five, tools/attn_order_ab.py; chunks of 2 ... 8 and block-major orders within 1 %); the rows still meet in the XCD's L2
+    const int nlh = gridDim.x / (2 * nb);
+    if (order && (nlh & 7) == 0) {
+      const int xcd = blockIdx.x & 7, u = blockIdx.x >> 3;
+      if (order == 1) blk = (blk + nb) % (2 * nb);
+      else {
+        // order = 100 v + CH: chunks of CH units per XCD; v & 1: the dQ blocks of a chunk first (else the dK / dV blocks); v & 2: block-major inside a role (else unit-major)
+        const int CH = order % 100, v = order / 100, per = CH * 2 * nb;
+        if (CH > 0 && (nlh >> 3) % CH == 0) {
+          const int cch = u / per, i = u % per, first = i / (CH * nb), j = i % (CH * nb);
+          const int role_dkv = (v & 1) ? first : 1 - first;
+          const int un = (v & 2) ? j % CH : j / nb, bl = (v & 2) ? j / CH : j % nb;
+          lh = (cch * CH + un) * 8 + xcd;
+          blk = (role_dkv ? nb : 0) + bl;
+        }
+      }
+    }
+  }
   if (blk < nb) {
     if (PIPE) attn_bwd_dq_body_p(smem, lh, blk, qkv, nullptr, dout, lse2, dvec, dqkv, dbias, S, nh, c, scale);
     else attn_bwd_dq_body(smem, lh, blk, qkv, nullptr, dout, lse2, dvec, dqkv, dbias, S, nh, c, scale);
@@ -1811,6 +1830,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_p_k(const bf16raw* qkv, bf16r
 
 
 int g_attn_bwd_pair = 1;  // pero_set_option("attn_bwd_pair", 0 / 1)
+int g_attn_order = 4;     // pero_set_option("attn_order", n): dispatch order of the paired backward's blocks (see attn_bwd_pair_k; 0 = a unit's four blocks side by side)
 int g_attn_lh = 0;        // pero_set_option("attn_lh", 0 / 1): S = 256 with D handed in and a bias gradient wanted -> the persistent (line, head) kernel
                           // attn_bwd_lh_k.  Same bits; measured 735-745 us against 725-735 us of the paired kernels at 1024 lines: off
 int g_attn_pipe = 1;      // pero_set_option("attn_pipe", 0 / 1): the bodies with software-pipelined operand reads (default) / the compiler-scheduled ones
@@ -1852,10 +1872,10 @@ extern "C" int pero_attention_bwd(const void* qkv, const void* out, const void* 
     const size_t lds = AT_DKV2_LDS > 2 * AT_TILE_BYTES ? AT_DKV2_LDS : 2 * AT_TILE_BYTES;
     if (g_attn_pipe)
       hipLaunchKernelGGL(attn_bwd_pair_k<true>, dim3(2 * grid.x), block, lds, st, (const bf16raw*)qkv, (const bf16raw*)dout, lse, dvec, (bf16raw*)dqkv,
-                         dbias ? work : nullptr, (int)S, (int)num_heads, c, scale);
+                         dbias ? work : nullptr, (int)S, (int)num_heads, c, scale, g_attn_order);
     else
       hipLaunchKernelGGL(attn_bwd_pair_k<false>, dim3(2 * grid.x), block, lds, st, (const bf16raw*)qkv, (const bf16raw*)dout, lse, dvec, (bf16raw*)dqkv,
-                         dbias ? work : nullptr, (int)S, (int)num_heads, c, scale);
+                         dbias ? work : nullptr, (int)S, (int)num_heads, c, scale, g_attn_order);
   } else {
   if (g_attn_pipe)
     hipLaunchKernelGGL(attn_bwd_dq_k<true>, grid, block, 2 * AT_TILE_BYTES, st, (const bf16raw*)qkv, (const bf16raw*)out, (const bf16raw*)dout, lse,

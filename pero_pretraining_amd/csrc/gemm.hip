@@ -368,6 +368,7 @@ __global__ __launch_bounds__(256) void gemm_generic(GemmP p) {
 extern int g_gemm_e_var;
 extern int g_attn_bwd_pair;           // attention.hip
 extern int g_attn_pipe;
+extern int g_attn_order;
 extern int g_attn_lh;
 extern int g_gemm_splitk_ws;          // gemm_e.hip
 extern int g_gemm_splitk_table;
@@ -385,6 +386,7 @@ extern "C" int pero_set_option(const char* name, int value) {
   if (name && !strcmp(name, "gemm_e_var")) { g_gemm_e_var = value; return PERO_OK; }
   if (name && !strcmp(name, "attn_bwd_pair")) { g_attn_bwd_pair = value; return PERO_OK; }
   if (name && !strcmp(name, "attn_pipe")) { g_attn_pipe = value; return PERO_OK; }
+  if (name && !strcmp(name, "attn_order")) { g_attn_order = value; return PERO_OK; }
   if (name && !strcmp(name, "attn_lh")) { g_attn_lh = value; return PERO_OK; }
   if (name && !strcmp(name, "splitk_workspace")) { g_gemm_splitk_ws = value; return PERO_OK; }
   if (name && !strcmp(name, "splitk_table")) { g_gemm_splitk_table = value; return PERO_OK; }
