@@ -1031,8 +1031,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_pair_k(const bf16raw* qkv, co
   const int nb = S >> 7;
   int lh, blk;
   attn_block_map(blockIdx.x, 2 * nb, gridDim.x / (2 * nb), lh, blk);
-  {   // Dispatch order inside an XCD (pero_set_option("attn_order", n); default 4): chunks of four units whose dK / dV blocks (the longer ones) go out ahead of their dQ blocks -
-      // 1 432 -> 1 397 us per 2048 lines (medians of five, tools/attn_order_ab.py; chunks of 2 ... 8 and block-major orders within 1 %); the rows still meet in the XCD's L2
+  {   // Dispatch order inside an XCD (pero_set_option("attn_order", n); default 32): chunks of 32 units whose 64 dK / dV blocks - one round of the XCD's 64 workgroup
+      // places - go out ahead of their 64 dQ blocks, so that the CUs of an XCD run ONE kind of block at a time: medians of six launches (tools/attn_order_ab.py, 2048 lines)
+      // 1 406 us side by side, 1 385 / 1 381 with chunks of 4 / 8, 1 414 with 16 (both kinds in one round again), 1 361 with 32, 1 388 with 64.  A chunk's rows are 8 MB:
+      // the dQ blocks find half of them in the XCD's L2, the rest in the memory-side cache.
     const int nlh = gridDim.x / (2 * nb);
     if (order && (nlh & 7) == 0) {
       const int xcd = blockIdx.x & 7, u = blockIdx.x >> 3;
@@ -1830,7 +1832,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_p_k(const bf16raw* qkv, bf16r
 
 
 int g_attn_bwd_pair = 1;  // pero_set_option("attn_bwd_pair", 0 / 1)
-int g_attn_order = 4;     // pero_set_option("attn_order", n): dispatch order of the paired backward's blocks (see attn_bwd_pair_k; 0 = a unit's four blocks side by side)
+int g_attn_order = 32;    // pero_set_option("attn_order", n): dispatch order of the paired backward's blocks (see attn_bwd_pair_k; 0 = a unit's four blocks side by side)
 int g_attn_lh = 0;        // pero_set_option("attn_lh", 0 / 1): S = 256 with D handed in and a bias gradient wanted -> the persistent (line, head) kernel
                           // attn_bwd_lh_k.  Same bits; measured 735-745 us against 725-735 us of the paired kernels at 1024 lines: off
 int g_attn_pipe = 1;      // pero_set_option("attn_pipe", 0 / 1): the bodies with software-pipelined operand reads (default) / the compiler-scheduled ones
