@@ -296,6 +296,14 @@ def layer_bwd(dt2, L, saved, n, s, h, dtype, side=None, dt2_is_dy2=False, prev=N
         dvec = torch.empty((a.shape[0], a.shape[1] // 128), device=a.device, dtype=torch.float32)
     da = linear_bwd(dy1, a, at.out_proj.weight, at.out_proj.bias, dtype, bias_grad_done=True, side=side,
                     dx_rowdot=(a, dvec) if dvec is not None else None)
+    return _layer_bwd_attn(da, dvec, dy1, L, saved, n, s, h, dtype, side, prev)
+
+
+def _layer_bwd_attn(da, dvec, dy1, L, saved, n, s, h, dtype, side, prev):
+    """The rest of a layer's backward behind the out-projection: attention and in_proj (da: gradient of the attention output, dvec: its row dots with
+    the output per head or None, dy1: the gradient that joins as the residual)."""
+    t, qkv, p, a = saved[0], saved[1], saved[2], saved[3]
+    at = L.self_attn
     fuse_bq = False
     if p.dim() == 2:
         # in_proj's bias gradient = column sums of dqkv: out of the attention kernels' staged output tiles
@@ -310,6 +318,84 @@ def layer_bwd(dt2, L, saved, n, s, h, dtype, side=None, dt2_is_dy2=False, prev=N
         if dy2_prev is not None:
             return dy2_prev, True
     return linear_bwd(dqkv, t, at.in_proj_weight, at.in_proj_bias, dtype, residual=dy1, side=side, bias_grad_done=fuse_bq), False
+
+
+ROW_SPARSE_LAST_LAYER = True   # bf16 mode: when the gradient of the backbone's output is nonzero on a KNOWN list of rows only (the masked positions of the head's
+                               # loss: masked_pretraining/model.py _HeadCEFn, ~15 % of the positions), the last layer's row-wise part - norm2, linear2, linear1,
+                               # norm1, the out-projection - runs its backward on those rows alone (gathered into whole 256-row tiles) and scatters into zero
+                               # matrices in front of the attention backward, which mixes the rows.  The dropped terms are products with exact zeros.
+
+_row_grad_hint = None
+row_sparse_steps = 0   # backward passes whose last layer ran on the listed rows (tests read it)
+
+
+def set_row_grad_hint(dense, index, compact, nrows):
+    """The producer of a row-sparse gradient announces it: `dense` (the tensor it returns to autograd) is zero outside the rows `index` (int64, device), whose
+    values are compact[:nrows] (rows nrows.. of compact are zero)."""
+    global _row_grad_hint
+    _row_grad_hint = (dense.data_ptr(), dense.numel(), index, compact, nrows)
+
+
+def take_row_grad_hint(dense):
+    """(index, compact, nrows) if `dense` is the announced tensor, else None; the announcement is consumed either way."""
+    global _row_grad_hint
+    h, _row_grad_hint = _row_grad_hint, None
+    if h is None or not ROW_SPARSE_LAST_LAYER or h[0] != dense.data_ptr() or h[1] != dense.numel():
+        return None
+    return h[2], h[3], h[4]
+
+
+def layer_bwd_rows(dtc, index, nrows, L, saved, n, s, h, dtype, side=None, prev=None):
+    """layer_bwd for a gradient of the layer's output that is nonzero on the rows `index` only: dtc = those rows (then zero rows up to a multiple of 256).
+    Returns what layer_bwd returns, or None when this layer's saved state does not allow it (the caller then runs layer_bwd on the dense gradient)."""
+    t, qkv, p, a, y1, mean1, rstd1, t1, hdn, y2, mean2, rstd2, bits, t2 = saved
+    if dtype != torch.bfloat16 or y1 is not None or y2 is not None or p.dim() != 2 or dtc.shape[0] % 256 or not DX_ON_WT:
+        return None
+    at = L.self_attn
+    n_pad, M, d = dtc.shape[0], t.shape[0], t.shape[1]
+
+    def rows_of(x):
+        return ops.gather_rows(x, index, n_rows_out=n_pad)
+
+    def vec_of(v):   # a per-row f32 statistic of the listed rows (pad rows: 1)
+        out = torch.ones(n_pad, device=v.device, dtype=v.dtype)
+        out[:nrows] = v[index]
+        return out
+
+    # norm2 (its dx column sums are linear2's bias gradient)
+    t2c = rows_of(t2)
+    dy2c = ops.layernorm_bwd_out(dtc, t2c, vec_of(rstd2), L.norm2.weight.detach(), L.norm2.bias.detach(), ensure_grad(L.norm2.weight), ensure_grad(L.norm2.bias),
+                                 ensure_grad(L.linear2.bias))
+    # linear2: the ReLU gate from the hidden rows themselves (their bit mask is laid out for whole tiles)
+    hdnc = rows_of(hdn)
+    fuse_b1 = FUSE_BIAS_GRAD and FUSE_B1_COLSUM and L.linear1.bias is not None and L.linear1.bias.requires_grad
+    dpre1c = linear_bwd(dy2c, hdnc, L.linear2.weight, L.linear2.bias, dtype, gate=hdnc, bias_grad_done=True, side=side,
+                        dx_colsum_into=ensure_grad(L.linear1.bias) if fuse_b1 else None)
+    del hdnc
+    # linear1 + norm1
+    t1c, r1c = rows_of(t1), vec_of(rstd1)
+    dy1c = linear_bwd_ln(dpre1c, t1c, L.linear1.weight, L.linear1.bias, dtype, dy2c, t1c, r1c, L.norm1, ensure_grad(at.out_proj.bias), side=side,
+                         bias_grad_done=fuse_b1)
+    if dy1c is None:
+        dt1c = linear_bwd(dpre1c, t1c, L.linear1.weight, L.linear1.bias, dtype, residual=dy2c, side=side, bias_grad_done=fuse_b1)
+        dy1c = ops.layernorm_bwd_out(dt1c, t1c, r1c, L.norm1.weight.detach(), L.norm1.bias.detach(), ensure_grad(L.norm1.weight), ensure_grad(L.norm1.bias),
+                                     ensure_grad(at.out_proj.bias))
+    del dpre1c
+    # out-projection (+ D = rowsum(dO * O) per head for the attention backward)
+    ac = rows_of(a)
+    nh = a.shape[1] // 128
+    dvecc = torch.empty((n_pad, nh), device=a.device, dtype=torch.float32) if FUSE_ROWDOT and a.shape[1] % 128 == 0 else None
+    dac = linear_bwd(dy1c, ac, at.out_proj.weight, at.out_proj.bias, dtype, bias_grad_done=True, side=side, dx_rowdot=(ac, dvecc) if dvecc is not None else None)
+    # back to all positions: exact zeros elsewhere
+    da = ops.scatter_add_rows(dac, index, ops.zeros((M, a.shape[1]), a.device, dtype))
+    dy1 = ops.scatter_add_rows(dy1c, index, ops.zeros((M, d), a.device, dtype))
+    dvec = None
+    if dvecc is not None:
+        dvec = ops.zeros((M, nh), a.device, torch.float32)
+        dvec[index] = dvecc[:nrows]
+    global row_sparse_steps
+    row_sparse_steps += 1
+    return _layer_bwd_attn(da, dvec, dy1, L, saved, n, s, h, dtype, side, prev)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -350,7 +436,8 @@ def backbone_fwd(mod, x, mask, offsets, dtype, save):
     return t, saved
 
 
-def backbone_bwd(mod, saved, dt, dtype, on_layer_done=None):
+def backbone_bwd(mod, saved, dt, dtype, on_layer_done=None, rows=None):
+    """rows = (index, compact, nrows): dt is zero outside the rows `index`, whose values are compact[:nrows] (take_row_grad_hint)."""
     a0, y0, mean0, rstd0, layers, n, s = saved
     nl = len(layers)
     side = SideStream(dt.device)
@@ -359,7 +446,12 @@ def backbone_bwd(mod, saved, dt, dtype, on_layer_done=None):
         prev = None
         if i > 0 and layers[i - 1][9] is None:   # the lower layer kept no pre-norm rows: its norm2 backward runs from its output (= this layer's input)
             prev = (layers[i - 1][11], mod.encoder_layers.layers[i - 1])
-        dt, is_dy2 = layer_bwd(dt, mod.encoder_layers.layers[i], layers[i], n, s, mod.num_heads, dtype, side, dt2_is_dy2=is_dy2, prev=prev)
+        res = None
+        if i == nl - 1 and rows is not None:
+            res = layer_bwd_rows(rows[1], rows[0], rows[2], mod.encoder_layers.layers[i], layers[i], n, s, mod.num_heads, dtype, side, prev=prev)
+        if res is None:
+            res = layer_bwd(dt, mod.encoder_layers.layers[i], layers[i], n, s, mod.num_heads, dtype, side, dt2_is_dy2=is_dy2, prev=prev)
+        dt, is_dy2 = res
         layers[i] = None
         if on_layer_done is not None:
             with side.comm_context():  # sees the layer's gradient kernels on the main and the side streams

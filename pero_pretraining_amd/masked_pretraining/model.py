@@ -164,6 +164,8 @@ class _HeadCEFn(torch.autograd.Function):
             dx = ops.zeros(x2.shape, x2.device, x2.dtype)
             ops.scatter_add_rows(dxm, index, dx)                            # reads the first n rows of dxm
             dx = dx.view(ctx.shape)
+            if dxm.dtype == torch.bfloat16:
+                F.set_row_grad_hint(dx, index, dxm, n)                      # the backbone's last layer may work from the listed rows (functional.layer_bwd_rows)
         return dx, None, None, None, None, None, None
 
 

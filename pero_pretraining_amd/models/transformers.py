@@ -74,8 +74,9 @@ class _BackboneFn(torch.autograd.Function):
     def backward(ctx, dt):
         if ctx.saved is None:
             raise RuntimeError("backbone backward called twice or without saved activations")
+        rows = F.take_row_grad_hint(dt)   # the head's loss announces a gradient that is zero outside its masked rows (functional.ROW_SPARSE_LAST_LAYER)
         dt = dt.to(ctx.dtype).contiguous()
-        F.backbone_bwd(ctx.mod, ctx.saved, dt, ctx.dtype, ctx.mod._on_layer_grads_ready)
+        F.backbone_bwd(ctx.mod, ctx.saved, dt, ctx.dtype, ctx.mod._on_layer_grads_ready, rows=rows)
         ctx.saved = None
         return (None,) * (5 + len(ctx.mod._param_list))
 

@@ -128,6 +128,58 @@ def test_config2_step_under_every_layernorm_path_stays_within_the_f32_step(cfg2)
     model.eval()
 
 
+def test_config2_last_layer_backward_on_the_masked_rows_gives_the_dense_gradients(cfg2):
+    """functional.ROW_SPARSE_LAST_LAYER (round 4): the loss reads the masked positions only, so the gradient of the backbone's output is zero on every other row and
+    the last layer's row-wise part (norm2, linear2, linear1, norm1, out-projection) runs its backward on the listed rows alone.  The dropped terms are products
+    with exact zeros and the tile kernels give a row the same bits at every batch size, so EVERY parameter gradient must equal the dense backward's up to the
+    order of the f32 additions (1e-5 of the largest entry; the two dense runs differ by as much), and the path must really have been taken."""
+    import pero_pretraining_amd as P
+    from pero_pretraining_amd import functional as F
+    model, images, labels, mask = cfg2
+    model.train()
+    offs = np.arange(16) * 5
+    rows = torch.nonzero(mask.reshape(-1) == 1).reshape(-1)   # the row list the trainer gets from the mask's host original (no device sync there)
+
+    def step(flag):
+        F.ROW_SPARSE_LAST_LAYER = flag
+        model.zero_grad()
+        model.backbone.set_offsets(offs)
+        with P.autocast(True):
+            res = model(images, labels, mask, rows=rows)
+        res["loss"].backward()
+        return float(res["loss"]), {k: p.grad.detach().clone().float() for k, p in model.named_parameters()}
+
+    try:
+        taken = F.row_sparse_steps
+        l0, g0 = step(False)
+        assert F.row_sparse_steps == taken
+        l1, g1 = step(True)
+        assert F.row_sparse_steps == taken + 1, "the head's row list did not reach the backbone"
+        assert F._row_grad_hint is None
+        assert l0 == l1
+        for k in g0:
+            ref = float(g0[k].abs().max())
+            assert float((g0[k] - g1[k]).abs().max()) <= 1e-5 * ref + 1e-12, k
+        # an all-rows mask is the dense case through the same code
+        full = torch.ones_like(mask)
+        frows = torch.arange(full.numel(), device=full.device)
+        F.ROW_SPARSE_LAST_LAYER = False
+        model.zero_grad(); model.backbone.set_offsets(offs)
+        with P.autocast(True):
+            model(images, labels, full, rows=frows)["loss"].backward()
+        ga = {k: p.grad.detach().clone().float() for k, p in model.named_parameters()}
+        F.ROW_SPARSE_LAST_LAYER = True
+        model.zero_grad(); model.backbone.set_offsets(offs)
+        with P.autocast(True):
+            model(images, labels, full, rows=frows)["loss"].backward()
+        for k, p in model.named_parameters():
+            ref = float(ga[k].abs().max())
+            assert float((ga[k] - p.grad.detach().float()).abs().max()) <= 1e-5 * ref + 1e-12, k
+    finally:
+        F.ROW_SPARSE_LAST_LAYER = True
+        model.eval()
+
+
 def test_config3_vq_argmin_is_idempotent_on_the_codebook():
     from pero_pretraining_amd import ops
     g = torch.Generator(device="cuda").manual_seed(5)
