@@ -48,16 +48,18 @@ CFG = dict(num_blocks=12, model_dim=512, num_heads=4, feedforward_dim=2048, voca
            patch=8, channels=3)
 
 
-def flops_per_line(c=CFG, masked_frac=None):
+def flops_per_line(c=CFG, masked_frac=None, last_layer_rows=False):
     """forward F = patch + L*(qkv + attn + out + ffn) + head; step = 3F.  With `masked_frac` the EXECUTED count:
-    the head's two backward products run on the masked rows only (the other rows of dlogits are exact zeros)."""
+    the head's two backward products run on the masked rows only (the other rows of dlogits are exact zeros); with `last_layer_rows` so do the
+    backward products of the LAST layer's feed-forward block and out-projection (functional.ROW_SPARSE_LAST_LAYER)."""
     S, d, L, ff, V = c["width"] // c["patch"], c["model_dim"], c["num_blocks"], c["feedforward_dim"], c["vocab"]
     kp = c["channels"] * c["height"] * c["patch"]
     head = 2 * S * d * V
     F = 2 * S * kp * d + L * (2 * S * d * 3 * d + 4 * S * S * d + 2 * S * d * d + 4 * S * d * ff) + head
     if masked_frac is None:
         return 3 * F
-    return 3 * F - 2 * head * (1.0 - masked_frac)
+    rows = 2 * (2 * S * d * d + 4 * S * d * ff) * (1.0 - masked_frac) if last_layer_rows else 0.0
+    return 3 * F - 2 * head * (1.0 - masked_frac) - rows
 
 
 def csrc_hash():
@@ -641,7 +643,7 @@ def main():
         final_loss = float(loss.detach()) if hasattr(loss, "detach") else float(loss)
         lines_per_s = world * args.batch * args.steps / elapsed
         step_flops = flops_per_line()
-        exec_flops = flops_per_line(masked_frac=0.15) if (args.head_backward == "masked" and not args.masked_head) else step_flops
+        exec_flops = flops_per_line(masked_frac=0.15, last_layer_rows=F.ROW_SPARSE_LAST_LAYER) if (args.head_backward == "masked" and not args.masked_head) else step_flops
         out.update({
             "value": round(lines_per_s, 2), "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "config": {"workload": "masked pretraining step incl. prepare_batch, 12-layer d=512 h=4 ff=2048 ViT, V=4096, 40x2048 u8 lines "
@@ -650,6 +652,7 @@ def main():
                        "parallelism": f"dp{world}", "optimizer": "fused Adam (f32 master weights)",
                        "weight_gradients_on_side_stream": bool(F.SIDE_STREAM_DW), "head_rows": model.head_rows,
                        "head_backward": args.head_backward,
+                       "last_layer_backward_rows": "masked (exact zeros elsewhere; the all-positions form is timed in option_dense_last_layer)" if F.ROW_SPARSE_LAST_LAYER else "all",
                        "gflop_per_line_step": round(step_flops / 1e9, 3), "gflop_per_line_step_executed": round(exec_flops / 1e9, 3)},
             "protocol": {"repeats": args.repeats, "statistic": "median", "repeats_ms_per_step": [round(e / args.steps * 1e3, 3) for e in repeats],
                          "inputs": "uint8 line images resident in HBM; labels from the host and the mask drawn on the host inside the timed "
@@ -706,6 +709,18 @@ def main():
                                          "note": "same loss, gradients and update; the head FORWARD too runs on the ~15 % masked positions only "
                                                  "(the reference computes and discards the rest); NOT the headline value"}
             model.head_rows = "all"
+            # ---- option: the last layer's row-wise backward over ALL positions (the headline runs it on the masked rows: exact zeros elsewhere)
+            from pero_pretraining_amd import functional as Fn
+            Fn.ROW_SPARSE_LAST_LAYER = False
+            for i in range(3):
+                step(i)
+            el, rp, _ = timer.median(step, osteps, reps, first=3)
+            out["option_dense_last_layer"] = {"value": round(world * args.batch * osteps / el, 2), "unit": "lines/s", "ms_per_step": round(el / osteps * 1e3, 3),
+                                              "note": "functional.ROW_SPARSE_LAST_LAYER = False: norm2 / linear2 / linear1 / norm1 / out-projection of the LAST layer "
+                                                      "run their backward over all positions, 85 % of which carry an exactly zero gradient (the loss reads the masked "
+                                                      "positions); same gradients to 1e-5 (tests/test_gpu_full_size.py); the headline works from the masked rows, as the "
+                                                      "head's backward has since round 2"}
+            Fn.ROW_SPARSE_LAST_LAYER = True
 
         if not args.no_roofline:
             per = timed_gemms(lambda n: [step(args.warmup + 7 + k) for k in range(n)], 2)
