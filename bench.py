@@ -548,6 +548,8 @@ def main():
     ap.add_argument("--no-options", action="store_true", help="skip the extra legs (resident step, PCIe-inclusive step, masked head)")
     ap.add_argument("--head-backward", default="masked", choices=["masked", "dense"],
                     help="head backward on the masked rows only (default: the other rows of dlogits are exact zeros) or over all rows")
+    ap.add_argument("--dense-last-layer", action="store_true",
+                    help="functional.ROW_SPARSE_LAST_LAYER = False for the whole run (the headline then equals option_dense_last_layer of a default run)")
     ap.add_argument("--masked-head", action="store_true",
                     help="OPTION, not the headline: head FORWARD + loss on the masked positions only (model.head_rows = 'masked'); "
                          "the default evaluates the head on every position like the reference")
@@ -599,6 +601,8 @@ def main():
         backend = dist.get_backend() + (" (REHEARSAL: ranks share devices, timings not meaningful)" if rehearse else "")
 
     from pero_pretraining_amd import functional as F
+    if args.dense_last_layer:
+        F.ROW_SPARSE_LAST_LAYER = False
     from pero_pretraining_amd.parallel import DataParallel
     F.SIDE_STREAM_DW = bool(args.side_stream) and not args.no_side_stream
     timer = Timer(device)
@@ -720,7 +724,7 @@ def main():
                                                       "run their backward over all positions, 85 % of which carry an exactly zero gradient (the loss reads the masked "
                                                       "positions); same gradients to 1e-5 (tests/test_gpu_full_size.py); the headline works from the masked rows, as the "
                                                       "head's backward has since round 2"}
-            Fn.ROW_SPARSE_LAST_LAYER = True
+            Fn.ROW_SPARSE_LAST_LAYER = not args.dense_last_layer
 
         if not args.no_roofline:
             per = timed_gemms(lambda n: [step(args.warmup + 7 + k) for k in range(n)], 2)
