@@ -336,6 +336,11 @@ def set_row_grad_hint(dense, index, compact, nrows):
     _row_grad_hint = (dense.data_ptr(), dense.numel(), index, compact, nrows)
 
 
+def drop_row_grad_hint():
+    global _row_grad_hint
+    _row_grad_hint = None
+
+
 def take_row_grad_hint(dense):
     """(index, compact, nrows) if `dense` is the announced tensor, else None; the announcement is consumed either way."""
     global _row_grad_hint

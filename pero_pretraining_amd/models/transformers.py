@@ -66,6 +66,7 @@ class _BackboneFn(torch.autograd.Function):
         save = any(ctx.needs_input_grad)
         if save:
             mod._grad_forwards = getattr(mod, "_grad_forwards", 0) + 1  # parallel.DataParallel overlaps only single-pass steps
+        F.drop_row_grad_hint()   # (an announcement a failed or abandoned backward left behind must not meet this pass's gradient)
         tokens, saved = F.backbone_fwd(mod, x, mask, offsets, dtype, save)
         ctx.mod, ctx.saved, ctx.dtype = mod, saved, dtype
         return tokens
