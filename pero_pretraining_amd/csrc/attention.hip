@@ -522,14 +522,16 @@ __global__ __launch_bounds__(128) void attn_bias_reduce_k(const float* partial, 
   const int per_head = nlines * nblk;  // workgroups of this head
   const int chunk = (per_head + gridDim.z - 1) / gridDim.z;
   const int i0 = blockIdx.z * chunk, i1 = i0 + chunk < per_head ? i0 + chunk : per_head;
-  float s0 = 0.f, s1 = 0.f;
+  // eight rows in flight per thread (two were 27 us for 25 MB of partial rows: one dependent load latency per pair)
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  auto at = [&](int i) -> float { return p[(((long long)(i / nblk) * nh + head) * nblk + i % nblk) * 128 + c]; };
   int i = i0;
-  for (; i + 2 <= i1; i += 2) {
-    s0 += p[(((long long)(i / nblk) * nh + head) * nblk + i % nblk) * 128 + c];
-    s1 += p[(((long long)((i + 1) / nblk) * nh + head) * nblk + (i + 1) % nblk) * 128 + c];
+  for (; i + 8 <= i1; i += 8) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) s[k] += at(i + k);
   }
-  if (i < i1) s0 += p[(((long long)(i / nblk) * nh + head) * nblk + i % nblk) * 128 + c];
-  if (i0 < i1) atomicAdd(dbias + (long long)which * nh * 128 + head * 128 + c, s0 + s1);
+  for (; i < i1; i++) s[0] += at(i);
+  if (i0 < i1) atomicAdd(dbias + (long long)which * nh * 128 + head * 128 + c, ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7])));
 }
 
 __device__ __forceinline__ void attn_bwd_dq_body(unsigned char* smem, int lh, int qb, const bf16raw* qkv, const bf16raw* out,
@@ -1866,7 +1868,7 @@ extern "C" int pero_attention_bwd(const void* qkv, const void* out, const void* 
     const int cus = pero_num_cus();
     hipLaunchKernelGGL(attn_bwd_lh_k, dim3((unsigned)(units < cus ? units : cus)), dim3(512), LH_LAUNCH_LDS, st, (const bf16raw*)qkv, (const bf16raw*)dout, lse,
                        (const float*)dvec, (bf16raw*)dqkv, work, (int)units, (int)num_heads, c, scale);
-    hipLaunchKernelGGL(attn_bias_reduce_k, dim3((unsigned)num_heads, 3, N >= 1024 ? 64 : 16), dim3(128), 0, st, work, dbias, (int)N, (int)num_heads, 1);
+    hipLaunchKernelGGL(attn_bias_reduce_k, dim3((unsigned)num_heads, 3, N >= 4096 ? 128 : N >= 1024 ? 64 : 16), dim3(128), 0, st, work, dbias, (int)N, (int)num_heads, 1);
     PERO_CHECK_LAUNCH("pero_attention_bwd");
     return PERO_OK;
   }
@@ -1893,7 +1895,7 @@ extern "C" int pero_attention_bwd(const void* qkv, const void* out, const void* 
                        (bf16raw*)dqkv, dbias ? work : nullptr, (int)S, (int)num_heads, c, scale);
   }
   if (dbias)
-    hipLaunchKernelGGL(attn_bias_reduce_k, dim3((unsigned)num_heads, 3, (N * (S / 128) >= 1024) ? 64 : 16), dim3(128), 0, st, work, dbias, (int)N, (int)num_heads, (int)(S / 128));
+    hipLaunchKernelGGL(attn_bias_reduce_k, dim3((unsigned)num_heads, 3, (N * (S / 128) >= 4096) ? 128 : (N * (S / 128) >= 1024) ? 64 : 16), dim3(128), 0, st, work, dbias, (int)N, (int)num_heads, (int)(S / 128));
   PERO_CHECK_LAUNCH("pero_attention_bwd");
   return PERO_OK;
 }
